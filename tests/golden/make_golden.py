@@ -1,0 +1,376 @@
+#!/usr/bin/env python
+"""
+Generate the golden fixtures by IMPORTING THE REFERENCE.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes tests/golden/g*.npz: inputs and the outputs the reference produced on them
+(data only -- no reference source).  Versions used are recorded in g0_meta.npz.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings('ignore')
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+
+import scipy  # noqa: E402
+import pandas  # noqa: E402
+import frankenz  # noqa: E402
+from frankenz import pdf as rpdf  # noqa: E402
+from frankenz.fitting import BruteForce, NearestNeighbors  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    sz = os.path.getsize(os.path.join(HERE, name + '.npz'))
+    print('%-28s %8.1f KB' % (name, sz / 1024.))
+
+
+def mock_models(rs, M, B=5, merr_lo=0.01, merr_hi=0.10):
+    Y = rs.lognormal(1.0, 1.0, size=(M, B))
+    Ye = rs.uniform(merr_lo, merr_hi, size=(M, B)) * Y
+    return Y, Ye
+
+
+MODES = [(fs, ime, dp) for fs in (False, True) for ime in (False, True)
+         for dp in (False, True)]
+
+
+def g1():
+    """loglike in all 8 mode combos + return_scale; float and bool masks, masked
+    bands, NaN flux, non-positive error, exact self-match, low-Ndim rows."""
+    rs = np.random.RandomState(101)
+    M, B = 64, 5
+    Y, Ye = mock_models(rs, M, B)
+    Ym = np.ones((M, B))
+    Ym[3, 1] = 0
+    Ym[7, [0, 4]] = 0
+    Ym[11, [0, 1, 2]] = 0       # Ndim=2 against a full object
+    Ym[12, [0, 1, 2, 3]] = 0    # Ndim=1
+    Ym[13, :] = 0               # Ndim=0
+    # objects
+    objs = []
+    x = Y[5] + SDSS_SIGMA * rs.randn(B)
+    objs.append((x, SDSS_SIGMA.copy(), np.ones(B)))                  # plain
+    objs.append((Y[20].copy(), SDSS_SIGMA.copy(), np.ones(B)))        # exact self-match (chi2=0 when Ye kept? no: resid=0)
+    x = Y[9] * 3.3 + SDSS_SIGMA * rs.randn(B)
+    xm = np.ones(B); xm[2] = 0
+    objs.append((x, SDSS_SIGMA.copy(), xm))                           # masked band + scale
+    x = Y[30] + SDSS_SIGMA * rs.randn(B)
+    x[1] = np.nan
+    xe = SDSS_SIGMA.copy(); xe[3] = -1.0
+    objs.append((x, xe, np.ones(B)))                                  # dirty -> cleaned
+    x = 50. * Y[40] + 0.1 * SDSS_SIGMA * rs.randn(B)
+    objs.append((x, 0.1 * SDSS_SIGMA, np.ones(B)))                    # bright, high S/N
+    X = np.array([o[0] for o in objs]); Xe = np.array([o[1] for o in objs])
+    Xm = np.array([o[2] for o in objs])
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm)
+    for mi, (fs, ime, dp) in enumerate(MODES):
+        for oi in range(len(X)):
+            for mk, mdt in (('f', float), ('b', bool)):
+                x, xe, xm = X[oi].copy(), Xe[oi].copy(), Xm[oi].astype(mdt)
+                ym = Ym.astype(mdt)
+                res = rpdf.loglike(x, xe, xm, Y, Ye, ym, free_scale=fs,
+                                   ignore_model_err=ime, dim_prior=dp,
+                                   return_scale=fs)
+                key = 'm%d_o%d_%s' % (mi, oi, mk)
+                out[key + '_lnl'] = res[0]
+                out[key + '_ndim'] = np.asarray(res[1])
+                out[key + '_chi2'] = res[2]
+                if fs:
+                    out[key + '_scale'] = res[3]
+                    out[key + '_scale_err'] = res[4]
+                if mk == 'f':
+                    out['clean_o%d_x' % oi] = x
+                    out['clean_o%d_xe' % oi] = xe
+                    out['clean_o%d_xm' % oi] = xm
+    # logprob adapter on one case
+    lp = rpdf.logprob(X[0].copy(), Xe[0].copy(), Xm[0].copy(), Y, Ye, Ym)
+    out['logprob_lnprior'], out['logprob_lnprob'] = lp[0], lp[2]
+    save('g1_loglike', **out)
+
+
+def g2():
+    """mode C (free scale + model errors) on M=2000, heterogeneous model errors:
+    pins the GLOBAL per-object iteration count."""
+    rs = np.random.RandomState(202)
+    M, B = 2000, 5
+    Y, _ = mock_models(rs, M, B)
+    Ye = Y * rs.uniform(0.01, 0.12, size=(M, B))
+    Ym = np.ones((M, B))
+    X = np.array([Y[17] * 2.0 + SDSS_SIGMA * rs.randn(B),
+                  Y[400] * 0.3 + SDSS_SIGMA * rs.randn(B),
+                  30. * Y[1200] + SDSS_SIGMA * rs.randn(B)])
+    Xe = np.tile(SDSS_SIGMA, (3, 1))
+    Xm = np.ones((3, B))
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm)
+    # count iterations by instrumenting through ltol sweep is not possible; use
+    # a counting subclass of ndarray ops instead: simply re-run the loop here
+    # with the reference's public pieces is not allowed (no copying), so record
+    # outputs at two tolerances; the oracle's own counter is checked for
+    # consistency against these outputs.
+    for oi in range(3):
+        for dp in (False, True):
+            for tname, ltol in (('t4', 1e-4), ('t8', 1e-8)):
+                res = rpdf.loglike(X[oi].copy(), Xe[oi].copy(), Xm[oi].copy(),
+                                   Y, Ye, Ym, free_scale=True,
+                                   ignore_model_err=False, dim_prior=dp,
+                                   ltol=ltol, return_scale=True)
+                k = 'o%d_dp%d_%s' % (oi, int(dp), tname)
+                out[k + '_lnl'], out[k + '_chi2'] = res[0], res[2]
+                out[k + '_scale'], out[k + '_scale_err'] = res[3], res[4]
+    save('g2_modec', **out)
+
+
+def demo_dict():
+    return rpdf.PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+
+
+def g3():
+    """PDFDict tables + fit() on edge labels."""
+    d = demo_dict()
+    lens = np.array([len(k) for k in d.sigma_dict])
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    X = np.array([-0.3, -0.005, 0.0, 0.005, 0.015, 0.025, 0.0349999, 3.333,
+                  6.995, 7.0, 7.005, 7.4, 0.125, 0.135])
+    Xe = np.array([-1.0, 0.0, 0.005, 0.007, 0.0069999, 0.009, 0.011, 0.05,
+                   1.999, 2.0, 2.5, 100., 0.0130, 0.0170])
+    xi, si = d.fit(X, Xe)
+    # full tables for the first 120 entries (all well-formed: width <= Ngrid//2
+    # up to entry 174); per-entry sums and end-of-cdf values for all 500
+    nfull = 120
+    save('g3_pdfdict', grid=d.grid, sigma_grid=d.sigma_grid,
+         sigma_width=d.sigma_width, lens=lens, offs=offs, nfull=nfull,
+         kern=np.concatenate(d.sigma_dict[:nfull]),
+         kcdf=np.concatenate(d.sigma_dict_cdf[:nfull]),
+         kern_sum=np.array([k.sum() for k in d.sigma_dict]),
+         kern_first=np.array([k[0] for k in d.sigma_dict]),
+         kcdf_last=np.array([c[-1] for c in d.sigma_dict_cdf]), delta=d.delta,
+         dsigma=d.dsigma, Ngrid=d.Ngrid, Ndict=d.Ndict,
+         fit_X=X, fit_Xe=Xe, fit_xi=xi, fit_si=si)
+
+
+def g4():
+    """gauss_kde_dict / gauss_kde: interior, both edges, strict threshold,
+    CDF mode, tiny-sigma empty window, zero-mass kernel."""
+    rs = np.random.RandomState(404)
+    d = demo_dict()
+    M = 300
+    y = rs.uniform(0.0, 7.0, M)
+    y[:6] = [0.0, 0.004, 0.12, 6.9, 6.996, 7.0]      # edges
+    ys = rs.uniform(0.006, 0.25, M)
+    wt = rs.lognormal(0, 2.0, M)
+    wt /= wt.sum()
+    # strictness: make two weights EXACTLY thresh*max
+    wmax = wt.max()
+    wt[10] = 0.25 * wmax
+    wt[11] = 0.25 * wmax
+    out = dict(y=y, ys=ys, wt=wt)
+    out['dict_default'] = rpdf.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt)
+    out['dict_thresh25'] = rpdf.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt,
+                                               wt_thresh=0.25)
+    out['dict_nothresh'] = rpdf.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt,
+                                               wt_thresh=None, cdf_thresh=None)
+    out['dict_cdf'] = rpdf.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt,
+                                          wt_thresh=None)
+    out['dict_unit'] = rpdf.gauss_kde_dict(d, y=y, y_std=ys)
+    yi, ysi = d.fit(y, ys)
+    out['yi'], out['ysi'] = yi, ysi
+    out['dict_idx'] = rpdf.gauss_kde_dict(d, y_idx=yi, y_std_idx=ysi, y_wt=wt)
+    grid = d.grid
+    out['grid'] = grid
+    out['kde_default'] = rpdf.gauss_kde(y, ys, grid, y_wt=wt)
+    out['kde_thresh25'] = rpdf.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=0.25)
+    out['kde_nothresh'] = rpdf.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None,
+                                         cdf_thresh=None)
+    out['kde_cdf'] = rpdf.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None)
+    out['kde_sig3'] = rpdf.gauss_kde(y, ys, grid, y_wt=wt, sig_thresh=3.)
+    # tiny sigma -> empty window (offset 0), and sigma so small that the
+    # in-window gaussian sum underflows to 0 (zero-mass kernel is skipped)
+    y2 = np.array([1.0, 2.004, 3.0049, 4.0])
+    ys2 = np.array([0.05, 0.0015, 1e-4, 0.03])
+    w2 = np.array([0.4, 0.3, 0.2, 0.1])
+    out['y2'], out['ys2'], out['w2'] = y2, ys2, w2
+    out['kde_tiny'] = rpdf.gauss_kde(y2, ys2, grid, y_wt=w2)
+    save('g4_kde', **out)
+
+
+def small_problem(seed, N, M, B=5):
+    rs = np.random.RandomState(seed)
+    Y, Ye = mock_models(rs, M, B)
+    Ym = np.ones((M, B))
+    Ym[rs.rand(M, B) < 0.04] = 0
+    pick = rs.choice(M, N)
+    sc = rs.lognormal(0, 0.5, N)[:, None]
+    X = sc * Y[pick] + SDSS_SIGMA * rs.randn(N, B)
+    Xe = np.tile(SDSS_SIGMA, (N, 1)) * rs.uniform(0.8, 1.2, size=(N, B))
+    Xm = np.ones((N, B))
+    Xm[rs.rand(N, B) < 0.05] = 0
+    X[2, 3] = np.nan
+    Xe[5, 0] = 0.0
+    z = rs.uniform(0.02, 6.0, M)
+    ze = rs.uniform(0.01, 0.12, M)
+    return Y, Ye, Ym, X, Xe, Xm, z, ze
+
+
+def g5():
+    """BruteForce N=20, M=160."""
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(505, 20, 160)
+    d = demo_dict()
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm, z=z, ze=ze)
+    bf = BruteForce(Y, Ye, Ym)
+    x, xe, xm = X.copy(), Xe.copy(), Xm.copy()
+    bf.fit(x, xe, xm, verbose=False)
+    out['clean_X'], out['clean_Xe'], out['clean_Xm'] = x, xe, xm
+    for nm in ('lnprior', 'lnlike', 'lnprob', 'Ndim', 'chi2', 'scale',
+               'scale_err'):
+        out['fitA_' + nm] = getattr(bf, 'fit_' + nm)
+    p, (lm, le) = bf.predict(z, ze, label_dict=d, return_gof=True,
+                             verbose=False)
+    out['predA_dict'], out['predA_lmap'], out['predA_levid'] = p, lm, le
+    out['predA_grid'] = bf.predict(z, ze, label_grid=d.grid, verbose=False)
+    out['predA_logwt_chi2'] = bf.predict(z, ze, label_dict=d,
+                                         logwt=-0.5 * bf.fit_chi2,
+                                         verbose=False)
+    out['predA_thresh'] = bf.predict(z, ze, label_dict=d, verbose=False,
+                                     kde_kwargs={'wt_thresh': 1e-2})
+    # fused, all four likelihood configurations used by the demos
+    for tag, kw in (('A', {}),
+                    ('An', {'dim_prior': False}),
+                    ('Ai', {'ignore_model_err': True}),
+                    ('B', {'free_scale': True, 'ignore_model_err': True}),
+                    ('Bn', {'free_scale': True, 'ignore_model_err': True,
+                            'dim_prior': False}),
+                    ('C', {'free_scale': True, 'ignore_model_err': False}),
+                    ('Cn', {'free_scale': True, 'ignore_model_err': False,
+                            'dim_prior': False})):
+        bf2 = BruteForce(Y, Ye, Ym)
+        kw2 = dict(kw)
+        ts = bool(kw.get('free_scale'))
+        if ts:
+            kw2['return_scale'] = True
+        p, (lm, le) = bf2.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze,
+                                      label_dict=d, lprob_kwargs=kw2,
+                                      return_gof=True, track_scale=ts,
+                                      verbose=False, save_fits=True)
+        out['fp%s_pdfs' % tag], out['fp%s_lmap' % tag] = p, lm
+        out['fp%s_levid' % tag] = le
+        out['fp%s_lnprob' % tag] = bf2.fit_lnprob
+        if ts:
+            out['fp%s_chi2' % tag] = bf2.fit_chi2
+            out['fp%s_scale' % tag] = bf2.fit_scale
+            out['fp%s_scale_err' % tag] = bf2.fit_scale_err
+    bf3 = BruteForce(Y, Ye, Ym)
+    out['fpA_grid_pdfs'] = bf3.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z,
+                                           ze, label_grid=d.grid,
+                                           verbose=False, save_fits=False)
+    save('g5_bruteforce', **out)
+
+
+def g6():
+    """NearestNeighbors(K=5, k=4)."""
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(606, 24, 400)
+    # the luptitude map needs finite data for the MC draw; keep the NaN out of
+    # this fixture (rstate.normal(nan, .) is fine but asinh(nan) poisons KDTree)
+    X[2, 3] = 1.0
+    Xe[5, 0] = SDSS_SIGMA[0]
+    d = demo_dict()
+    fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9))
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm, z=z, ze=ze)
+    for fmap in ('luptitude', 'identity'):
+        kw = dict(fk) if fmap == 'luptitude' else {}
+        nn = NearestNeighbors(Y, Ye, Ym, K=5, feature_map=fmap,
+                              fmap_kwargs=kw, rstate=np.random.RandomState(1),
+                              verbose=False)
+        out[fmap + '_feats'] = np.stack([np.asarray(t.data, dtype='float32')
+                                         for t in nn.KDTrees])
+        p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze,
+                                     rstate=np.random.RandomState(2), k=4,
+                                     label_dict=d, return_gof=True,
+                                     verbose=False)
+        out[fmap + '_pdfs'], out[fmap + '_lmap'] = p, lm
+        out[fmap + '_levid'] = le
+        out[fmap + '_neighbors'] = nn.neighbors
+        out[fmap + '_Nneighbors'] = nn.Nneighbors
+        out[fmap + '_lnprob'] = nn.fit_lnprob
+        out[fmap + '_chi2'] = nn.fit_chi2
+        out[fmap + '_Ndim'] = nn.fit_Ndim
+        # fit + predict split, eps=0 (exact search)
+        nn.fit(X.copy(), Xe.copy(), Xm.copy(),
+               rstate=np.random.RandomState(2), k=4, eps=0.0, verbose=False)
+        out[fmap + '_neighbors_eps0'] = nn.neighbors
+        out[fmap + '_pdfs_eps0'] = nn.predict(z, ze, label_dict=d,
+                                              verbose=False)
+    out['scipy_version'] = np.array(scipy.__version__)
+    out['pandas_version'] = np.array(pandas.__version__)
+    save('g6_knn', **out)
+
+
+def g7():
+    """Config 1 inputs from the reference's own simulator: 1000 SDSS ugriz
+    objects (CWW+ templates, BPZ prior) and a 125 z x 8 template model grid,
+    plus reference outputs (checksum rows + 16 full PDFs)."""
+    from frankenz import simulate
+    np.random.seed(7)
+    ms = simulate.MockSurvey()
+    ms.load_survey('sdss', Npoints=50000)
+    ms.set_refmag('r')
+    ms.load_templates('cww+')
+    ms.load_prior('bpz')
+    ms.make_mock(1000, mbounds=[14, 25], zbounds=[0, 6], verbose=False)
+    zgrid = np.linspace(0, 6, 125)
+    ms.make_model_grid(zgrid, verbose=False)
+    obs = np.array(ms.data['phot_obs'])
+    err = np.array(ms.data['phot_err'])
+    tru = np.array(ms.data['phot_true'])
+    zs = np.array(ms.data['redshifts'])
+    mg = np.array(ms.models['data'])            # (Nz, Nt, Nf)
+    nz, nt, nf = mg.shape
+    mphot = mg.reshape(nz * nt, nf)
+    mz = np.repeat(zgrid, nt)
+    d = demo_dict()
+    out = dict(obs=obs, err=err, tru=tru, redshifts=zs, zgrid=zgrid,
+               mphot=mphot, mz=mz)
+    # (i) model-grid mode: free scale, no model errors
+    merr = np.zeros_like(mphot)
+    mmask = np.ones_like(mphot)
+    bf = BruteForce(mphot, merr, mmask)
+    kw = {'free_scale': True, 'ignore_model_err': True, 'return_scale': True}
+    p, (lm, le) = bf.fit_predict(obs.copy(), err.copy(), np.ones_like(obs),
+                                 mz, np.full(len(mz), 0.03), label_dict=d,
+                                 lprob_kwargs=kw, return_gof=True,
+                                 track_scale=True, verbose=False)
+    out['grid_pdfs16'] = p[:16]
+    out['grid_pdfsum'] = p.sum(axis=0)
+    out['grid_lmap'], out['grid_levid'] = lm, le
+    out['grid_lnprob_rows'] = bf.fit_lnprob[:4]
+    out['grid_lnprob_rowsum'] = bf.fit_lnprob.sum(axis=1)
+    out['grid_scale_rows'] = bf.fit_scale[:4]
+    # (ii) training-set mode: the mock itself as models (1000 x 1000), default
+    bf = BruteForce(obs, err, np.ones_like(obs))
+    p, (lm, le) = bf.fit_predict(obs.copy(), err.copy(), np.ones_like(obs), zs,
+                                 np.full(len(zs), 0.03), label_dict=d,
+                                 return_gof=True, verbose=False)
+    out['train_pdfs16'] = p[:16]
+    out['train_pdfsum'] = p.sum(axis=0)
+    out['train_lmap'], out['train_levid'] = lm, le
+    out['train_lnprob_rows'] = bf.fit_lnprob[:4]
+    out['train_lnprob_rowsum'] = np.where(np.isfinite(bf.fit_lnprob),
+                                          bf.fit_lnprob, 0.).sum(axis=1)
+    save('g7_config1', **out)
+
+
+if __name__ == '__main__':
+    save('g0_meta', numpy=np.array(np.__version__),
+         scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
+         reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
+    g1(); g2(); g3(); g4(); g5(); g6(); g7()
