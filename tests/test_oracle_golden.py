@@ -1,0 +1,246 @@
+"""The oracle (oracle/frankenz_oracle.py) against EVERY golden vector generated
+from the reference (tests/golden/make_golden.py).  CPU only.  This is what pins
+the oracle; the HIP parity tests then compare the kernels with the oracle."""
+import numpy as np
+import pytest
+
+import frankenz_oracle as fo
+from conftest import load_golden, SDSS_SIGMA
+
+MODES = [(fs, ime, dp) for fs in (False, True) for ime in (False, True)
+         for dp in (False, True)]
+TIGHT = dict(rtol=1e-12, atol=1e-12)
+
+
+def eq(a, b, **kw):
+    kw = kw or TIGHT
+    np.testing.assert_allclose(a, b, equal_nan=True, **kw)
+
+
+def demo_dict():
+    return fo.KernelDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+
+
+@pytest.mark.parametrize('mi', range(8))
+def test_g1_loglike_all_modes(mi):
+    g = load_golden('g1_loglike')
+    fs, ime, dp = MODES[mi]
+    Y, Ye, Ym = g['Y'], g['Ye'], g['Ym']
+    for oi in range(len(g['X'])):
+        for mk, mdt in (('f', float), ('b', bool)):
+            x, xe, xm = g['X'][oi].copy(), g['Xe'][oi].copy(), g['Xm'][oi].astype(mdt)
+            res = fo.loglike(x, xe, xm, Y, Ye, Ym.astype(mdt), free_scale=fs,
+                             ignore_model_err=ime, dim_prior=dp, return_scale=fs)
+            key = 'm%d_o%d_%s' % (mi, oi, mk)
+            tol = dict(rtol=1e-9, atol=1e-9) if (fs and not ime) else TIGHT
+            eq(res[0], g[key + '_lnl'], **tol)
+            eq(res[1], g[key + '_ndim'])
+            assert np.asarray(res[1]).dtype == g[key + '_ndim'].dtype
+            eq(res[2], g[key + '_chi2'], **tol)
+            if fs:
+                eq(res[3], g[key + '_scale'], **tol)
+                eq(res[4], g[key + '_scale_err'], **tol)
+            if mk == 'f':   # in-place clean is caller-visible
+                eq(x, g['clean_o%d_x' % oi]); eq(xe, g['clean_o%d_xe' % oi])
+                eq(xm, g['clean_o%d_xm' % oi])
+
+
+def test_g1_special_values_present():
+    """the fixture really exercises -inf / nan / +inf rows (not just finite)."""
+    g = load_golden('g1_loglike')
+    allv = np.concatenate([g[k] for k in g.files if k.endswith('_lnl')])
+    assert np.isneginf(allv).any() and np.isnan(allv).any()
+
+
+def test_g1_logprob_adapter():
+    g = load_golden('g1_loglike')
+    r = fo.logprob(g['X'][0].copy(), g['Xe'][0].copy(), g['Xm'][0].copy(),
+                   g['Y'], g['Ye'], g['Ym'])
+    eq(r[0], g['logprob_lnprior']); eq(r[2], g['logprob_lnprob'])
+    assert len(r) == 5
+
+
+def test_g2_mode_c_global_stop_rule():
+    g = load_golden('g2_modec')
+    Y, Ye, Ym = g['Y'], g['Ye'], g['Ym']
+    for oi in range(3):
+        for dp in (False, True):
+            for tname, ltol in (('t4', 1e-4), ('t8', 1e-8)):
+                r = fo.lnlike_scaled(g['X'][oi].copy(), g['Xe'][oi].copy(),
+                                     g['Xm'][oi].copy(), Y, Ye, Ym,
+                                     dim_prior=dp, ltol=ltol, return_scale=True,
+                                     return_niter=True)
+                k = 'o%d_dp%d_%s' % (oi, int(dp), tname)
+                eq(r[0], g[k + '_lnl'], rtol=1e-10, atol=1e-10)
+                eq(r[2], g[k + '_chi2'], rtol=1e-10, atol=1e-10)
+                eq(r[3], g[k + '_scale'], rtol=1e-10, atol=1e-12)
+                eq(r[4], g[k + '_scale_err'], rtol=1e-10, atol=1e-12)
+                assert r[5] >= 1
+    # the stop rule is global: a tile evaluated alone stops earlier and differs
+    r_all = fo.lnlike_scaled(g['X'][0].copy(), g['Xe'][0].copy(), g['Xm'][0].copy(),
+                             Y, Ye, Ym, dim_prior=False, return_niter=True)
+    r_sub = fo.lnlike_scaled(g['X'][0].copy(), g['Xe'][0].copy(), g['Xm'][0].copy(),
+                             Y[:100], Ye[:100], Ym[:100], dim_prior=False,
+                             return_niter=True)
+    assert r_sub[3] <= r_all[3]
+
+
+def test_g3_pdfdict_tables_and_fit():
+    g = load_golden('g3_pdfdict')
+    d = demo_dict()
+    assert d.Ngrid == int(g['Ngrid']) and d.Ndict == int(g['Ndict'])
+    eq(d.grid, g['grid']); eq(d.sigma_grid, g['sigma_grid'])
+    eq(d.delta, g['delta']); eq(d.dsigma, g['dsigma'])
+    np.testing.assert_array_equal(d.sigma_width, g['sigma_width'])
+    np.testing.assert_array_equal([len(k) for k in d.sigma_dict], g['lens'])
+    nf = int(g['nfull'])
+    eq(np.concatenate(d.sigma_dict[:nf]), g['kern'], rtol=1e-14, atol=0)
+    eq(np.concatenate(d.sigma_dict_cdf[:nf]), g['kcdf'], rtol=1e-14, atol=0)
+    eq([k.sum() for k in d.sigma_dict], g['kern_sum'], rtol=1e-13, atol=0)
+    eq([k[0] for k in d.sigma_dict], g['kern_first'], rtol=1e-14, atol=0)
+    eq([c[-1] for c in d.sigma_dict_cdf], g['kcdf_last'], rtol=1e-13, atol=0)
+    xi, si = d.fit(g['fit_X'], g['fit_Xe'])
+    np.testing.assert_array_equal(xi, g['fit_xi'])
+    np.testing.assert_array_equal(si, g['fit_si'])
+
+
+def test_g4_kde_variants():
+    g = load_golden('g4_kde')
+    d = demo_dict()
+    y, ys, wt, grid = g['y'], g['ys'], g['wt'], g['grid']
+    eq(fo.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt), g['dict_default'])
+    eq(fo.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=0.25), g['dict_thresh25'])
+    eq(fo.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=None),
+       g['dict_nothresh'])
+    eq(fo.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None), g['dict_cdf'])
+    eq(fo.gauss_kde_dict(d, y=y, y_std=ys), g['dict_unit'])
+    yi, ysi = d.fit(y, ys)
+    np.testing.assert_array_equal(yi, g['yi']); np.testing.assert_array_equal(ysi, g['ysi'])
+    eq(fo.gauss_kde_dict(d, y_idx=yi, y_std_idx=ysi, y_wt=wt), g['dict_idx'])
+    eq(fo.gauss_kde(y, ys, grid, y_wt=wt), g['kde_default'])
+    eq(fo.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=0.25), g['kde_thresh25'])
+    eq(fo.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None, cdf_thresh=None), g['kde_nothresh'])
+    eq(fo.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None), g['kde_cdf'])
+    eq(fo.gauss_kde(y, ys, grid, y_wt=wt, sig_thresh=3.), g['kde_sig3'])
+    eq(fo.gauss_kde(g['y2'], g['ys2'], grid, y_wt=g['w2']), g['kde_tiny'])
+    # strictness really is exercised: thresh25 differs from a >= rule
+    sel_gt = wt > 0.25 * wt.max()
+    sel_ge = wt >= 0.25 * wt.max()
+    assert sel_ge.sum() == sel_gt.sum() + 2
+
+
+def test_g5_bruteforce_fit_predict():
+    g = load_golden('g5_bruteforce')
+    d = demo_dict()
+    Y, Ye, Ym, z, ze = g['Y'], g['Ye'], g['Ym'], g['z'], g['ze']
+    X, Xe, Xm = g['X'].copy(), g['Xe'].copy(), g['Xm'].copy()
+    fit = fo.bruteforce_fit(X, Xe, Xm, Y, Ye, Ym)
+    eq(X, g['clean_X']); eq(Xe, g['clean_Xe']); eq(Xm, g['clean_Xm'])
+    for nm in ('lnprior', 'lnlike', 'lnprob', 'Ndim', 'chi2', 'scale', 'scale_err'):
+        eq(fit[nm], g['fitA_' + nm])
+        assert fit[nm].dtype == g['fitA_' + nm].dtype
+    p, lm, le = fo.bruteforce_predict(fit['lnprob'], z, ze, label_dict=d)
+    eq(p, g['predA_dict']); eq(lm, g['predA_lmap']); eq(le, g['predA_levid'])
+    p, _, _ = fo.bruteforce_predict(fit['lnprob'], z, ze, label_grid=d.grid)
+    eq(p, g['predA_grid'])
+    p, _, _ = fo.bruteforce_predict(-0.5 * fit['chi2'], z, ze, label_dict=d)
+    eq(p, g['predA_logwt_chi2'])
+    p, _, _ = fo.bruteforce_predict(fit['lnprob'], z, ze, label_dict=d, wt_thresh=1e-2)
+    eq(p, g['predA_thresh'])
+    with pytest.raises(ValueError):
+        fo.bruteforce_predict(fit['lnprob'], z, ze)
+
+
+FUSED = [('A', {}), ('An', {'dim_prior': False}), ('Ai', {'ignore_model_err': True}),
+         ('B', {'free_scale': True, 'ignore_model_err': True}),
+         ('Bn', {'free_scale': True, 'ignore_model_err': True, 'dim_prior': False}),
+         ('C', {'free_scale': True, 'ignore_model_err': False}),
+         ('Cn', {'free_scale': True, 'ignore_model_err': False, 'dim_prior': False})]
+
+
+@pytest.mark.parametrize('tag,kw', FUSED)
+def test_g5_bruteforce_fused(tag, kw):
+    g = load_golden('g5_bruteforce')
+    d = demo_dict()
+    p, lm, le = fo.bruteforce_fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(),
+                                          g['Y'], g['Ye'], g['Ym'], g['z'], g['ze'],
+                                          label_dict=d, **kw)
+    tol = dict(rtol=1e-9, atol=1e-12) if tag.startswith('C') else dict(rtol=1e-11, atol=1e-13)
+    eq(p, g['fp%s_pdfs' % tag], **tol)
+    eq(lm, g['fp%s_lmap' % tag], **tol); eq(le, g['fp%s_levid' % tag], **tol)
+    if kw.get('free_scale'):
+        fit = fo.bruteforce_fit(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(),
+                                g['Y'], g['Ye'], g['Ym'], track_scale=True,
+                                return_scale=True, **kw)
+        eq(fit['scale'], g['fp%s_scale' % tag], **tol)
+        eq(fit['scale_err'], g['fp%s_scale_err' % tag], **tol)
+        eq(fit['chi2'], g['fp%s_chi2' % tag], **tol)
+        eq(fit['lnprob'], g['fp%s_lnprob' % tag], **tol)
+
+
+def test_g5_fused_grid_kde():
+    g = load_golden('g5_bruteforce')
+    d = demo_dict()
+    p, _, _ = fo.bruteforce_fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(),
+                                        g['Y'], g['Ye'], g['Ym'], g['z'], g['ze'],
+                                        label_grid=d.grid)
+    eq(p, g['fpA_grid_pdfs'], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize('fmap', ['luptitude', 'identity'])
+def test_g6_knn(fmap):
+    g = load_golden('g6_knn')
+    d = demo_dict()
+    fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9)) if fmap == 'luptitude' else {}
+    Y, Ye, Ym = g['Y'], g['Ye'], g['Ym']
+    feats = fo.knn_train(Y, Ye, 5, fmap, np.random.RandomState(1), **fk)
+    assert feats.dtype == np.float32
+    np.testing.assert_array_equal(feats, g[fmap + '_feats'])     # bit-exact MC sets
+    q = fo.knn_query_features(g['X'], g['Xe'], fmap, np.random.RandomState(2), **fk)
+    # the same stream as ONE (N,B) draw
+    q2 = fo._fmap(fmap)(np.random.RandomState(2).normal(g['X'], g['Xe']), g['Xe'], **fk)[0]
+    eq(q, q2, rtol=0, atol=0)
+    tab = fo.knn_neighbors_exact(feats, q, 4)
+    p, lm, le, nbrs, nn, lnp = fo.knn_fit_predict(
+        g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), Y, Ye, Ym, tab, g['z'], g['ze'],
+        label_dict=d)
+    # exact search == scipy KDTree with eps=0 (no distance ties in this fixture)
+    np.testing.assert_array_equal(nbrs, g[fmap + '_neighbors_eps0'])
+    eq(p, g[fmap + '_pdfs_eps0'], rtol=1e-11, atol=1e-13)
+    # eps=1e-3 (reference default) may legitimately differ on near-ties: where
+    # the neighbour SETS agree, everything downstream must agree
+    same = [set(nbrs[i, :nn[i]]) == set(g[fmap + '_neighbors'][i, :g[fmap + '_Nneighbors'][i]])
+            for i in range(len(nn))]
+    same = np.array(same)
+    assert same.mean() > 0.8
+    rows = np.where(same & (nbrs == g[fmap + '_neighbors']).all(axis=1))[0]
+    assert len(rows) > 0
+    eq(p[rows], g[fmap + '_pdfs'][rows], rtol=1e-11, atol=1e-13)
+    eq(lm[rows], g[fmap + '_lmap'][rows]); eq(le[rows], g[fmap + '_levid'][rows])
+    eq(lnp[rows], g[fmap + '_lnprob'][rows])
+
+
+def test_g7_config1_reference_mock():
+    g = load_golden('g7_config1')
+    d = demo_dict()
+    obs, err = g['obs'], g['err']
+    n = 48   # the first 48 objects (16 full PDFs + gof for all 48)
+    kw = {'free_scale': True, 'ignore_model_err': True}
+    mphot = g['mphot']
+    p, lm, le = fo.bruteforce_fit_predict(obs[:n].copy(), err[:n].copy(), np.ones((n, 5)),
+                                          mphot, np.zeros_like(mphot), np.ones_like(mphot),
+                                          g['mz'], np.full(len(g['mz']), 0.03),
+                                          label_dict=d, **kw)
+    eq(p[:16], g['grid_pdfs16'], rtol=1e-10, atol=1e-14)
+    eq(lm, g['grid_lmap'][:n], rtol=1e-11, atol=0); eq(le, g['grid_levid'][:n], rtol=1e-11, atol=0)
+    fit = fo.bruteforce_fit(obs[:4].copy(), err[:4].copy(), np.ones((4, 5)), mphot,
+                            np.zeros_like(mphot), np.ones_like(mphot), track_scale=True,
+                            return_scale=True, **kw)
+    eq(fit['lnprob'], g['grid_lnprob_rows'], rtol=1e-11, atol=1e-11)
+    eq(fit['scale'], g['grid_scale_rows'], rtol=1e-11, atol=0)
+    # training-set mode (default likelihood; the self-match gives chi2=0 -> -inf)
+    p, lm, le = fo.bruteforce_fit_predict(obs[:n].copy(), err[:n].copy(), np.ones((n, 5)),
+                                          obs, err, np.ones_like(obs), g['redshifts'],
+                                          np.full(len(obs), 0.03), label_dict=d)
+    eq(p[:16], g['train_pdfs16'], rtol=1e-10, atol=1e-14)
+    eq(lm, g['train_lmap'][:n], rtol=1e-11, atol=0); eq(le, g['train_levid'][:n], rtol=1e-11, atol=0)
