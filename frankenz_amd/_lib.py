@@ -1,0 +1,104 @@
+"""ctypes binding of include/frankenz_hip.h.  Fails loudly if the HIP library is
+missing or does not export the whole ABI -- there is no fallback path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("FRANKENZ_HIP_LIB",
+                          os.path.join(_HERE, "csrc", "libfrankenz_hip.so"))
+
+
+class LikeOpts(C.Structure):
+    _fields_ = [("free_scale", C.c_int32), ("ignore_model_err", C.c_int32),
+                ("dim_prior", C.c_int32), ("max_iter", C.c_int32),
+                ("ltol", C.c_double)]
+
+
+class KdeOpts(C.Structure):
+    _fields_ = [("wt_thresh", C.c_double), ("use_wt_thresh", C.c_int32),
+                ("normalize", C.c_int32), ("cdf_thresh", C.c_double)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_planes", C.c_double), ("n_planes", C.c_int64),
+                ("ms_stats", C.c_double), ("n_stats", C.c_int64),
+                ("ms_kde", C.c_double), ("n_kde", C.c_int64),
+                ("ms_modec", C.c_double), ("n_modec", C.c_int64),
+                ("ms_knn", C.c_double), ("n_knn", C.c_int64),
+                ("ms_other", C.c_double), ("n_other", C.c_int64)]
+
+
+_P = C.c_void_p
+_I64, _I32, _F64 = C.c_int64, C.c_int32, C.c_double
+
+# name -> (restype, argtypes): exactly the declarations of include/frankenz_hip.h
+ABI = {
+    "fz_last_error": (C.c_char_p, []),
+    "fz_device_count": (C.c_int, []),
+    "fz_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "fz_ctx_destroy": (None, [_P]),
+    "fz_sync": (C.c_int, [_P]),
+    "fz_timing_reset": (C.c_int, [_P]),
+    "fz_timing_get": (C.c_int, [_P, C.POINTER(Timing)]),
+    "fz_set_workspace_limit": (C.c_int, [_P, _I64]),
+    "fz_models_upload": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
+    "fz_kdedict_upload": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
+    "fz_labels_upload_dict": (C.c_int, [_P, _P, _P, _I64]),
+    "fz_labels_upload_grid": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _F64, _F64]),
+    "fz_clean": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
+    "fz_fit": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts), _P, _P, _P, _P, _P]),
+    "fz_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts),
+                                 C.POINTER(KdeOpts), _P, _P, _P]),
+    "fz_predict_logwt": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(KdeOpts), _P, _P, _P]),
+    "fz_knn_upload_trees": (C.c_int, [_P, _P, _I32, _I64, _I32]),
+    "fz_knn_query": (C.c_int, [_P, _P, _I64, _I32, _F64, _P]),
+    "fz_knn_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
+                                     C.POINTER(KdeOpts)] + [_P] * 10),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfrankenz_hip.so and bind every ABI symbol (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "frankenz_amd: HIP library not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+# error code -> Python exception, mirroring what the reference raises
+_EXC = {-2: MemoryError, -3: IndexError, -4: ValueError, -5: NotImplementedError,
+        -6: NotImplementedError, -7: RuntimeError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().fz_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, RuntimeError)(msg)
+
+
+def ptr(a):
+    """void* of a NumPy array, a torch tensor (host or device) or a raw int."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return int(a)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError("cannot take a pointer of %r" % type(a))

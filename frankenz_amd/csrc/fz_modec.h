@@ -1,0 +1,130 @@
+// Mode C: free scale WITH model errors -- the fixed-point iteration of
+// pdf.py:196-223 and its per-object GLOBAL stop rule
+//     while max_j |lnl_new_j - lnl_j| > ltol
+// (Python builtin max over an ndarray: NaNs are skipped unless element 0 is NaN).
+//
+// The rule couples all M models of one object, so the state (scale, lnl, chi2,
+// shape) of a chunk of objects is kept in (Nc,M) planes in HBM and one kernel
+// launch advances every still-active object by one iteration; a tiny kernel then
+// applies the stop rule per object.  Objects that have stopped are frozen, which
+// reproduces the reference's per-object iteration count exactly.
+#pragma once
+#include "fz_device.h"
+
+namespace fz {
+
+struct ModeCState {
+    double* s;    // scale           (Nc,M)
+    double* l;    // Gaussian lnl    (Nc,M)
+    double* c;    // chi2            (Nc,M)
+    double* sh;   // shape           (Nc,M)
+    unsigned long long* err;   // (Nc) max |dlnl| as ordered bits
+    int* firstnan;             // (Nc) |dlnl[0]| is NaN
+    int* active;               // (Nc)
+    int* nactive;              // (1)
+};
+
+template <int BT, bool MASKED>
+struct ModeC {
+    ModelView mv;
+    ObjView ov;       // v = xe^2
+    int nband;
+
+    // one solve of (scale, chi2, lnl) for variance var_b = xe2_b + (s_prev*ye_b)^2;
+    // s_prev = 1 gives the initial pass of pdf.py:171-194.
+    __device__ __forceinline__ void solve(int64_t i, int64_t j, double sprev, double& s, double& lnl,
+                                          double& chi2, double& shape, int& ndim) const {
+        uint32_t jb = MASKED ? (ov.bits[i] & mv.bits[j]) : 0xffffffffu;
+        ndim = MASKED ? __popc(jb) : nband;
+        double var[BT], y[BT], x[BT], tm[BT];
+        double inter = 0.0; shape = 0.0;
+        double slog = 0.0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            y[b] = mv.y[(int64_t)b * mv.Mp + j];
+            x[b] = ov.x[i * BT + b];
+            tm[b] = MASKED ? (((jb >> b) & 1u) ? 1.0 : 0.0) : 1.0;
+            double ye2 = mv.ye2[(int64_t)b * mv.Mp + j];
+            var[b] = ov.v[i * BT + b] + (sprev * sprev) * ye2;      // xe^2 + (s*ye)^2
+            inter += tm[b] * y[b] * x[b] / var[b];
+            shape += tm[b] * (y[b] * y[b]) / var[b];
+            if (b < nband) slog += log(var[b]);                     // unmasked, pdf.py:193-194
+        }
+        s = inter / shape;
+        chi2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            double d = x[b] - s * y[b];
+            chi2 += tm[b] * (d * d) / var[b];
+        }
+        lnl = -0.5 * chi2 - 0.5 * ((double)ndim * FZ_LN2PI + slog);
+    }
+};
+
+template <class MC>
+__global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_t Nc, int64_t M, int init) {
+    const int64_t tiles = (M + 255) / 256;
+    const int64_t i = blockIdx.x / tiles;
+    const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
+    if (!init && !st.active[i]) return;                  // block-uniform
+    const bool valid = j < M;
+    double e = 0.0;
+    if (valid) {
+        const int64_t k = i * M + j;
+        double s, l, c, sh; int nd;
+        if (init) {
+            mc.solve(i, j, 1.0, s, l, c, sh, nd);
+        } else {
+            const double lold = st.l[k];
+            mc.solve(i, j, st.s[k], s, l, c, sh, nd);
+            e = fabs(l - lold);
+            if (j == 0 && e != e) st.firstnan[i] = 1;
+        }
+        st.s[k] = s; st.l[k] = l; st.c[k] = c; st.sh[k] = sh;
+    }
+    if (init) return;
+    // block max, NaNs dropped (a > b is false for NaN)
+    if (!(e == e)) e = 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e = fmax(e, __shfl_xor(e, o, 64));
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        e = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(&st.err[i], (unsigned long long)__double_as_longlong(e));   // e >= 0: bit order == value order
+    }
+}
+
+__global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nc) return;
+    if (!st.active[i]) return;
+    const double e = __longlong_as_double((long long)st.err[i]);
+    const bool go = !st.firstnan[i] && (e > ltol);       // `while lerr > ltol`
+    st.err[i] = 0ull;
+    if (go) atomicAdd(st.nactive, 1);
+    else st.active[i] = 0;
+}
+
+// after convergence: dim prior (pdf.py:226-229) and the output planes
+__global__ __launch_bounds__(256) void k_modec_final(ModeCState st, ModelView mv, const uint32_t* obits,
+                                                     int masked, int nband, int dim_prior,
+                                                     const double* lgtab, int64_t Nc, int64_t M,
+                                                     double* lnl, double* chi2, int64_t* ndim,
+                                                     double* scale, double* serr) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= Nc * M) return;
+    const int64_t i = k / M, j = k % M;
+    const int nd = masked ? __popc(obits[i] & mv.bits[j]) : nband;
+    double l = st.l[k];
+    const double c = st.c[k];
+    if (dim_prior) l = chi2_logpdf(0.5 * ((double)nd - 1.0) - 1.0, c, lgtab[nd]);
+    if (lnl) lnl[k] = l;
+    if (chi2) chi2[k] = c;
+    if (ndim) ndim[k] = nd;
+    if (scale) scale[k] = st.s[k];
+    if (serr) serr[k] = sqrt(1.0 / st.sh[k]);
+}
+
+}  // namespace fz

@@ -1,0 +1,181 @@
+"""
+Thin object wrapper over one ``fz_ctx`` (one per GPU).  Everything numeric happens
+inside libfrankenz_hip.so; this file only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KdeOpts, LikeOpts, Timing, check, ptr
+
+_LIKE_KEYS = ("free_scale", "ignore_model_err", "dim_prior", "ltol", "return_scale")
+
+
+def like_opts(lprob_kwargs, max_iter=0):
+    """lprob_kwargs of pdf.logprob (pdf.py:326-328) -> fz_like_opts."""
+    kw = dict(lprob_kwargs or {})
+    extra = set(kw) - set(_LIKE_KEYS)
+    if extra:
+        raise NotImplementedError(
+            "lprob_kwargs %s are not understood by the HIP likelihood "
+            "(supported: %s)" % (sorted(extra), ", ".join(_LIKE_KEYS)))
+    return LikeOpts(int(bool(kw.get("free_scale", False))),
+                    int(bool(kw.get("ignore_model_err", False))),
+                    int(bool(kw.get("dim_prior", True))), int(max_iter),
+                    float(kw.get("ltol", 1e-4)))
+
+
+def kde_opts(kde_kwargs, normalize=True):
+    """kde_kwargs of gauss_kde / gauss_kde_dict -> fz_kde_opts.  ``wt_thresh=None``
+    with ``cdf_thresh=None`` means no thresholding (pdf.py:495-496, 578-579)."""
+    kw = dict(kde_kwargs or {})
+    wt = kw.pop("wt_thresh", 1e-3)
+    cdf = kw.pop("cdf_thresh", 2e-4)
+    kw.pop("sig_thresh", None)
+    kw.pop("dx", None)
+    if kw:
+        raise NotImplementedError("kde_kwargs %s are not supported" % sorted(kw))
+    if wt is None and cdf is None:
+        return KdeOpts(-np.inf, 1, int(normalize), 0.0)
+    if wt is None:
+        return KdeOpts(0.0, 0, int(normalize), float(cdf))
+    return KdeOpts(float(wt), 1, int(normalize), 0.0 if cdf is None else float(cdf))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine(object):
+    """One device context.  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.fz_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self.M = self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- uploads ----------------------------------------------------------
+    def upload_models(self, models, models_err, models_mask):
+        y, ye, ym = _f64(models), _f64(models_err), _f64(models_mask)
+        if y.ndim != 2 or ye.shape != y.shape or ym.shape != y.shape:
+            raise ValueError("models, models_err, models_mask must share a (Nmodel, Nfilt) shape")
+        check(self.lib.fz_models_upload(self.h, ptr(y), ptr(ye), ptr(ym), y.shape[0], y.shape[1]))
+        self.M, self.B = y.shape
+
+    def upload_dict(self, pdfdict):
+        lens = np.array([len(k) for k in pdfdict.sigma_dict], dtype=np.int64)
+        offs = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        kern = _f64(np.concatenate(pdfdict.sigma_dict))
+        kcdf = _f64(np.concatenate(pdfdict.sigma_dict_cdf))
+        widths = np.ascontiguousarray(pdfdict.sigma_width, dtype=np.int64)
+        check(self.lib.fz_kdedict_upload(self.h, int(pdfdict.Ngrid), len(lens), ptr(widths),
+                                         ptr(offs), ptr(kern), ptr(kcdf)))
+
+    def upload_labels_dict(self, y_idx, y_std_idx):
+        yi = np.ascontiguousarray(y_idx, dtype=np.int64)
+        si = np.ascontiguousarray(y_std_idx, dtype=np.int64)
+        check(self.lib.fz_labels_upload_dict(self.h, ptr(yi), ptr(si), len(yi)))
+
+    def upload_labels_grid(self, y, y_std, grid, dx=None, sig_thresh=5.0):
+        y, ys, g = _f64(y), _f64(y_std), _f64(grid)
+        if dx is None:
+            dx = g[1] - g[0]
+        check(self.lib.fz_labels_upload_grid(self.h, ptr(y), ptr(ys), len(y), ptr(g), len(g),
+                                             float(dx), float(sig_thresh)))
+
+    def set_labels(self, labels, label_errs, label_dict=None, label_grid=None, kde_kwargs=None):
+        """bruteforce.py:598-599 / 361-369: dictionary path if a PDFDict is given,
+        else the direct KDE on ``label_grid``.  Returns Nx."""
+        if label_dict is None and label_grid is None:
+            raise ValueError("`label_dict` or `label_grid` must be specified.")
+        kw = kde_kwargs or {}
+        if label_dict is not None:
+            yi, si = label_dict.fit(np.asarray(labels), np.asarray(label_errs))
+            self.upload_dict(label_dict)
+            self.upload_labels_dict(yi, si)
+            return label_dict.Ngrid
+        self.upload_labels_grid(labels, label_errs, label_grid, dx=kw.get("dx"),
+                                sig_thresh=kw.get("sig_thresh", 5.0))
+        return len(label_grid)
+
+    # -- compute ----------------------------------------------------------
+    def fit(self, x, xe, xm, opts, lnlike=None, chi2=None, ndim=None, scale=None, scale_err=None,
+            n=None):
+        n = len(x) if n is None else n
+        check(self.lib.fz_fit(self.h, ptr(x), ptr(xe), ptr(xm), n, C.byref(opts), ptr(lnlike),
+                              ptr(chi2), ptr(ndim), ptr(scale), ptr(scale_err)))
+
+    def fit_predict(self, x, xe, xm, opts, kopts, pdfs, lmap=None, levid=None, n=None):
+        n = len(x) if n is None else n
+        check(self.lib.fz_fit_predict(self.h, ptr(x), ptr(xe), ptr(xm), n, C.byref(opts),
+                                      C.byref(kopts), ptr(pdfs), ptr(lmap), ptr(levid)))
+
+    def predict_logwt(self, logwt, kopts, pdfs, lmap=None, levid=None, is_log=True, n=None):
+        n = len(logwt) if n is None else n
+        check(self.lib.fz_predict_logwt(self.h, ptr(logwt), n, int(bool(is_log)), C.byref(kopts),
+                                        ptr(pdfs), ptr(lmap), ptr(levid)))
+
+    def clean(self, x, xe, xm):
+        check(self.lib.fz_clean(self.h, ptr(x), ptr(xe), ptr(xm), x.shape[0], x.shape[1]))
+
+    def sync(self):
+        check(self.lib.fz_sync(self.h))
+
+    def timing_reset(self):
+        check(self.lib.fz_timing_reset(self.h))
+
+    def timing(self):
+        t = Timing()
+        check(self.lib.fz_timing_get(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def set_workspace_limit(self, nbytes):
+        check(self.lib.fz_set_workspace_limit(self.h, int(nbytes)))
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine for ``device`` (default: LOCAL_RANK or 0)."""
+    import os
+    if device is None:
+        device = int(os.environ.get("FRANKENZ_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+        ndev = _lib.load().fz_device_count()
+        if ndev > 0:
+            device %= ndev
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]
+
+
+class HostObjects(object):
+    """float64 C-contiguous staging of (data, data_err, data_mask) that writes the
+    in-place clean of pdf.py:310-311 back into the caller's arrays."""
+
+    def __init__(self, data, data_err, data_mask):
+        self.src = (data, data_err, data_mask)
+        self.x, self.xe, self.xm = _f64(data), _f64(data_err), _f64(data_mask)
+        if self.x.ndim != 2 or self.xe.shape != self.x.shape or self.xm.shape != self.x.shape:
+            raise ValueError("data, data_err, data_mask must share a (Ndata, Nfilt) shape")
+
+    def writeback(self):
+        for dst, buf in zip(self.src, (self.x, self.xe, self.xm)):
+            if isinstance(dst, np.ndarray) and dst is not buf and not np.shares_memory(dst, buf):
+                dst[...] = buf

@@ -1,0 +1,155 @@
+"""
+Function-level surface of ``frankenz.pdf`` for the hot path (reference
+frankenz/pdf.py): ``logprob`` / ``loglike`` (pdf.py:238-411), ``gauss_kde`` /
+``gauss_kde_dict`` (pdf.py:444-622), ``PDFDict`` (pdf.py:778-852) and the k-NN
+feature maps ``luptitude`` / ``magnitude`` (pdf.py:625-657, 695-734).
+
+The likelihood and KDE arithmetic runs on the GPU through the C ABI.  ``PDFDict``
+(a one-off table of a few hundred short kernels) and the feature maps (O(N*B)
+elementwise set-up for the neighbour search) are host-side set-up, as in the
+reference; their tables are uploaded verbatim so the device reproduces the
+reference's kernels, malformed entries included.
+"""
+import math
+
+import numpy as np
+
+from .engine import HostObjects, get_engine, kde_opts, like_opts
+
+__all__ = ["loglike", "logprob", "gaussian", "gauss_kde", "gauss_kde_dict", "magnitude",
+           "luptitude", "PDFDict"]
+
+
+def _ndim_dtype(data_mask, models_mask):
+    """np.sum(data_mask * models_mask, axis=1) keeps the masks' arithmetic type
+    (pdf.py:82-83): bool/int masks give int64 counts, float masks float64."""
+    t = np.result_type(np.asarray(data_mask).dtype, np.asarray(models_mask).dtype)
+    return np.float64 if np.issubdtype(t, np.floating) else np.int64
+
+
+def loglike(data, data_err, data_mask, models, models_err, models_mask, free_scale=False,
+            ignore_model_err=False, dim_prior=True, ltol=1e-4, return_scale=False, device=None,
+            *args, **kwargs):
+    """One object against all models (pdf.py:238-323).  ``data``, ``data_err`` and
+    ``data_mask`` are cleaned IN PLACE exactly like the reference (pdf.py:310-311).
+    Returns ``(lnlike, Ndim, chi2[, scale, scale_err])``."""
+    eng = get_engine(device)
+    eng.upload_models(models, models_err, models_mask)
+    obj = HostObjects(np.atleast_2d(data), np.atleast_2d(data_err), np.atleast_2d(data_mask))
+    M = eng.M
+    lnl, chi2 = np.empty((1, M)), np.empty((1, M))
+    ndim = np.empty((1, M), dtype=np.int64)
+    sc = se = None
+    if free_scale and return_scale:
+        sc, se = np.empty((1, M)), np.empty((1, M))
+    opts = like_opts(dict(free_scale=free_scale, ignore_model_err=ignore_model_err,
+                          dim_prior=dim_prior, ltol=ltol))
+    eng.fit(obj.x, obj.xe, obj.xm, opts, lnl, chi2, ndim, sc, se)
+    # in-place clean visible to the caller
+    for dst, buf in ((data, obj.x), (data_err, obj.xe), (data_mask, obj.xm)):
+        if isinstance(dst, np.ndarray) and not np.shares_memory(dst, buf):
+            dst[...] = buf.reshape(dst.shape)
+    nd = ndim[0].astype(_ndim_dtype(data_mask, models_mask))
+    if free_scale and return_scale:
+        return lnl[0], nd, chi2[0], sc[0], se[0]
+    return lnl[0], nd, chi2[0]
+
+
+def logprob(data, data_err, data_mask, models, models_err, models_mask, free_scale=False,
+            ignore_model_err=False, dim_prior=True, ltol=1e-4, return_scale=False, *args,
+            **kwargs):
+    """pdf.py:326-411: ``(lnprior=0, lnlike, lnprob, Ndim, chi2[, scale, scale_err])``."""
+    res = loglike(data, data_err, data_mask, models, models_err, models_mask,
+                  free_scale=free_scale, ignore_model_err=ignore_model_err, dim_prior=dim_prior,
+                  ltol=ltol, return_scale=return_scale, *args, **kwargs)
+    lnl = res[0]
+    return (np.zeros_like(lnl), lnl, lnl[:]) + tuple(res[1:])
+
+
+def gaussian(mu, std, x):
+    """N(x | mu, std) on a grid (pdf.py:414-425) -- host helper used to build the
+    dictionary tables."""
+    d = (np.asarray(x) - mu) / std
+    return np.exp(-0.5 * np.square(d)) / (math.sqrt(2.0 * math.pi) * std)
+
+
+class PDFDict(object):
+    """Grid + dictionary of truncated Gaussian kernels (pdf.py:778-852).  Same
+    attributes as the reference: ``Ngrid, min, max, delta, grid, Ndict, sigma_grid,
+    dsigma, sigma_width, sigma_dict, sigma_dict_cdf`` and ``fit``."""
+
+    def __init__(self, pdf_grid, sigma_grid, sigma_trunc=5.):
+        self.Ngrid = len(pdf_grid)
+        self.min, self.max = min(pdf_grid), max(pdf_grid)
+        self.delta = pdf_grid[1] - pdf_grid[0]
+        self.grid = np.array(pdf_grid)
+        self.Ndict = len(sigma_grid)
+        self.sigma_grid = np.array(sigma_grid)
+        self.dsigma = sigma_grid[1] - sigma_grid[0]
+        # half-widths in grid cells; the slice below is taken literally so entries
+        # wider than half the grid come out malformed just like pdf.py:814-816
+        self.sigma_width = np.ceil(self.sigma_grid * sigma_trunc / self.delta).astype('int')
+        mid = int(self.Ngrid / 2)
+        self.sigma_dict = []
+        self.sigma_dict_cdf = []
+        for s, w in zip(self.sigma_grid, self.sigma_width):
+            k = gaussian(self.grid[mid], s, self.grid[mid - w:mid + w + 1])
+            self.sigma_dict.append(k)
+            self.sigma_dict_cdf.append(np.cumsum(k))
+
+    def fit(self, X, Xe):
+        """(value, error) -> (grid index, dictionary index) (pdf.py:843-852): mean
+        index by round-half-even and NOT clamped; error index clamped."""
+        X, Xe = np.asarray(X), np.asarray(Xe)
+        X_idx = ((X - self.grid[0]) / self.delta).round().astype('int')
+        Xe_idx = np.array(np.round((Xe - self.sigma_grid[0]) / self.dsigma), dtype='int')
+        np.clip(Xe_idx, 0, self.Ndict - 1, out=Xe_idx)
+        return X_idx, Xe_idx
+
+
+def gauss_kde(y, y_std, x, dx=None, y_wt=None, sig_thresh=5., wt_thresh=1e-3, cdf_thresh=2e-4,
+              device=None, *args, **kwargs):
+    """Direct weighted Gaussian KDE on grid ``x`` (pdf.py:444-526), un-normalised."""
+    eng = get_engine(device)
+    y = np.asarray(y, dtype=float)
+    wt = np.ones(len(y)) if y_wt is None else np.ascontiguousarray(y_wt, dtype=np.float64)
+    eng.upload_labels_grid(y, y_std, x, dx=dx, sig_thresh=sig_thresh)
+    out = np.empty((1, len(x)))
+    ko = kde_opts(dict(wt_thresh=wt_thresh, cdf_thresh=cdf_thresh), normalize=False)
+    eng.predict_logwt(wt.reshape(1, -1), ko, out, is_log=False)
+    return out[0]
+
+
+def gauss_kde_dict(pdfdict, y=None, y_std=None, y_idx=None, y_std_idx=None, y_wt=None,
+                   wt_thresh=1e-3, cdf_thresh=2e-4, device=None, *args, **kwargs):
+    """Dictionary KDE (pdf.py:529-622), un-normalised."""
+    if y_idx is not None and y_std_idx is not None:
+        pass
+    elif y is not None and y_std is not None:
+        y_idx, y_std_idx = pdfdict.fit(y, y_std)
+    else:
+        raise ValueError("At least one pair of (`y`, `y_std`) or (`y_idx`, `y_idx_std`) must "
+                         "be specified.")
+    eng = get_engine(device)
+    wt = np.ones(len(y_idx)) if y_wt is None else np.ascontiguousarray(y_wt, dtype=np.float64)
+    eng.upload_dict(pdfdict)
+    eng.upload_labels_dict(y_idx, y_std_idx)
+    out = np.empty((1, pdfdict.Ngrid))
+    ko = kde_opts(dict(wt_thresh=wt_thresh, cdf_thresh=cdf_thresh), normalize=False)
+    eng.predict_logwt(wt.reshape(1, -1), ko, out, is_log=False)
+    return out[0]
+
+
+def magnitude(phot, err, zeropoints=1., *args, **kwargs):
+    """AB magnitudes and errors (pdf.py:625-657); k-NN feature map."""
+    phot, err = np.asarray(phot), np.asarray(err)
+    return -2.5 * np.log10(phot / zeropoints), 2.5 / math.log(10.) * err / phot
+
+
+def luptitude(phot, err, skynoise=1., zeropoints=1., *args, **kwargs):
+    """asinh magnitudes and errors (pdf.py:695-734); the default k-NN feature map."""
+    phot, err = np.asarray(phot), np.asarray(err)
+    mag = -2.5 / math.log(10.) * (np.arcsinh(phot / (2. * skynoise)) + np.log(skynoise / zeropoints))
+    mag_err = np.sqrt(np.square(2.5 * np.log10(np.e) * err)
+                      / (np.square(2. * skynoise) + np.square(phot)))
+    return mag, mag_err

@@ -1,0 +1,138 @@
+/*
+ * frankenz_hip.h -- C ABI of libfrankenz_hip.so: the MI355X (gfx950) engine for
+ * frankenz's brute-force photometric likelihood -> weighted Gaussian-KDE PDF path.
+ *
+ * This is the drop-in boundary.  The reference (joshspeagle/frankenz v0.3.5) is
+ * pure Python/NumPy and has no FFI, so each entry point names the reference
+ * function (file:line) whose arithmetic it replaces; INTEGRATION.md shows the
+ * ctypes stub a frankenz maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; the message is available
+ *    from fz_last_error() (thread-local).
+ *  - all floating-point data is float64, indices are int64, matrices are
+ *    C-contiguous row-major exactly as the reference's NumPy arrays are.
+ *  - every array pointer may be a HOST pointer or a DEVICE (hipMalloc'd) pointer;
+ *    the library detects which (hipPointerGetAttributes) and stages host arrays
+ *    through its own buffers.  Output pointers may be NULL = "not wanted".
+ *  - masks are float64 0/1 (the reference's demos use np.ones_like(phot)).
+ *  - one fz_ctx per device; a ctx is not thread-safe.
+ */
+#ifndef FRANKENZ_HIP_H
+#define FRANKENZ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fz_ctx fz_ctx;
+
+/* lprob_kwargs of frankenz.pdf.logprob / loglike (pdf.py:238-240, 326-328). */
+typedef struct fz_like_opts {
+    int32_t free_scale;       /* pdf.py:313  free_scale        (default 0) */
+    int32_t ignore_model_err; /* pdf.py:76   ignore_model_err  (default 0) */
+    int32_t dim_prior;        /* pdf.py:90   dim_prior         (default 1) */
+    int32_t max_iter;         /* guard for the unbounded loop at pdf.py:199;
+                                 <=0 means 10000.  Hitting it is an error.   */
+    double  ltol;             /* pdf.py:199  ltol              (default 1e-4) */
+} fz_like_opts;
+
+/* kde_kwargs of gauss_kde / gauss_kde_dict (pdf.py:444-445, 529-531). */
+typedef struct fz_kde_opts {
+    double  wt_thresh;     /* relative-amplitude threshold (strict >), 1e-3     */
+    int32_t use_wt_thresh; /* 1: wt_thresh rule (pdf.py:507-510 / 589-591).
+                              0: the reference's CDF rule (wt_thresh=None);
+                                 not implemented on the device -> error.
+                              "no thresholding" is wt_thresh=-inf, use=1.       */
+    int32_t normalize;     /* 1: pdf /= pdf.sum() (bruteforce.py:370, 629)      */
+    double  cdf_thresh;    /* carried for the error message only                */
+} fz_kde_opts;
+
+/* accumulated device time per kernel family since fz_timing_reset (HIP events on
+ * the context's own stream). */
+typedef struct fz_timing {
+    double  ms_planes;  int64_t n_planes;   /* materialising fit kernel       */
+    double  ms_stats;   int64_t n_stats;    /* pass 1: max + logsumexp        */
+    double  ms_kde;     int64_t n_kde;      /* pass 2: threshold + KDE stack  */
+    double  ms_modec;   int64_t n_modec;    /* mode-C fixed-point iterations  */
+    double  ms_knn;     int64_t n_knn;      /* brute-force top-k search       */
+    double  ms_other;   int64_t n_other;    /* prep/clean/transposes          */
+} fz_timing;
+
+const char* fz_last_error(void);
+int  fz_device_count(void);
+
+int  fz_ctx_create(int device, fz_ctx** out);
+void fz_ctx_destroy(fz_ctx* ctx);
+int  fz_sync(fz_ctx* ctx);
+int  fz_timing_reset(fz_ctx* ctx);
+int  fz_timing_get(fz_ctx* ctx, fz_timing* out);
+/* byte budget for internal (N x M) work planes (mode C state, host staging). */
+int  fz_set_workspace_limit(fz_ctx* ctx, int64_t bytes);
+
+/* BruteForce.__init__ (bruteforce.py:36-64): the model set (M,B) x3. */
+int  fz_models_upload(fz_ctx* ctx, const double* models, const double* models_err,
+                      const double* models_mask, int64_t M, int32_t B);
+
+/* PDFDict tables (pdf.py:800-819): Ngrid, Ndict, sigma_width[D], ragged kernels
+ * and their running sums flattened with offsets[D+1] (lengths are as built by
+ * the reference, malformed entries included; they are rejected only if a label
+ * maps onto one). */
+int  fz_kdedict_upload(fz_ctx* ctx, int64_t G, int64_t D, const int64_t* widths,
+                       const int64_t* offsets, const double* kern, const double* kcdf);
+
+/* labels already mapped by PDFDict.fit (pdf.py:843-852) -> gauss_kde_dict path
+ * (pdf.py:599-620).  Returns -3 (IndexError semantics) if a label's window lies
+ * wholly off the grid, -4 (ValueError) if it maps onto a malformed entry. */
+int  fz_labels_upload_dict(fz_ctx* ctx, const int64_t* y_idx, const int64_t* y_std_idx,
+                           int64_t M);
+/* raw labels for the direct gauss_kde path (pdf.py:489-502, 519-524). */
+int  fz_labels_upload_grid(fz_ctx* ctx, const double* y, const double* y_std, int64_t M,
+                           const double* grid, int64_t G, double dx, double sig_thresh);
+
+/* pdf.loglike's in-place clean (pdf.py:309-311) over N objects: x, xe, xm (N,B)
+ * are MODIFIED (host or device).  fz_fit / fz_fit_predict call it themselves. */
+int  fz_clean(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N, int32_t B);
+
+/* BruteForce._fit (bruteforce.py:127-205) with lprob_func = pdf.logprob
+ * (pdf.py:326-411 -> _loglike pdf.py:27-100 / _loglike_s pdf.py:103-235).
+ * Output planes are (N,M); any may be NULL.  x/xe/xm are cleaned in place. */
+int  fz_fit(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+            const fz_like_opts* opts, double* lnlike, double* chi2, int64_t* ndim,
+            double* scale, double* scale_err);
+
+/* BruteForce._fit_predict with save_fits=False (bruteforce.py:505-631): never
+ * materialises (N,M).  pdfs is (N,G); lmap/levid (N) may be NULL. */
+int  fz_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+                    const fz_like_opts* opts, const fz_kde_opts* kde,
+                    double* pdfs, double* lmap, double* levid);
+
+/* BruteForce._predict (bruteforce.py:303-372): rows of logwt (N,M) -> PDFs.
+ * is_log=0 treats the rows as linear weights y_wt and skips the softmax
+ * (gauss_kde / gauss_kde_dict called directly, pdf.py:444, 529). */
+int  fz_predict_logwt(fz_ctx* ctx, const double* logwt, int64_t N, int32_t is_log,
+                      const fz_kde_opts* kde, double* pdfs, double* lmap, double* levid);
+
+/* ---- Monte-Carlo k-nearest-neighbour variant (knn.py) ---- */
+/* K float32 feature sets (K,M,F) as fed to KDTree (knn.py:177-186). */
+int  fz_knn_upload_trees(fz_ctx* ctx, const float* feats, int32_t K, int64_t M, int32_t F);
+/* exact k-NN of N float64 queries (N,F) in each of the K sets, p-norm 2,
+ * the flattened (N,K*k) table of knn.py:834-837; entries beyond
+ * distance_upper_bound are M (KDTree's "missing" index). */
+int  fz_knn_query(fz_ctx* ctx, const double* q, int64_t N, int32_t k,
+                  double distance_upper_bound, int64_t* idx);
+/* knn.py:840-872: first-appearance de-dup of each row, likelihood on the subset,
+ * weights, KDE.  Outputs padded like knn.py:812-821: neighbors (N,W) with -99,
+ * nnbr (N), planes (N,W) with -inf/+inf/0/1 padding; any may be NULL. */
+int  fz_knn_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+                        const int64_t* idx, int64_t W, const fz_like_opts* opts,
+                        const fz_kde_opts* kde, int64_t* neighbors, int64_t* nnbr,
+                        double* lnlike, double* chi2, int64_t* ndim, double* scale,
+                        double* scale_err, double* pdfs, double* lmap, double* levid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRANKENZ_HIP_H */
