@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""
+bench.py -- object-template likelihood evals/s (+ PDFs/s) of the fused
+BruteForce.fit_predict path (bruteforce.py:505-631, save_fits=False) on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus 8 --steps 3 --warmup 1
+
+One "step" = one pass of the hot path over one batch: N_obj objects x N_model
+models x 5 bands -> N_obj PDFs on the 701-point redshift grid.  Default workload is
+BASELINE.json's headline configuration (1e6 x 1e5 x 5, config index 2).  Inputs are
+synthetic (SURVEY.md section 8d generator) and already resident in HBM when the timed
+region starts; outputs stay in HBM.  Multi-GPU: the object axis is sharded, every
+rank runs the same per-GPU batch (weak scaling), no collective inside the step;
+the optional --gather adds the RCCL all-gather of the PDF shards.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])   # SDSS ugriz 1-sigma depths
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (public spec; = FP64 matrix peak)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic flops per object-model evaluation (add/mul/div/log/exp = 1, fma = 2)
+FLOPS_FUSED = {"A": 58, "B": 64}
+FLOPS_PASS = {"A": 54, "B": 60}  # one pass (likelihood 50/56 + max,sub,exp,add)
+
+MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True}}
+
+
+def make_problem(n_obj, n_model, seed):
+    """lognormal model fluxes, SDSS-depth noise."""
+    rs = np.random.RandomState(seed)
+    B = 5
+    Y = rs.lognormal(mean=1.0, sigma=1.0, size=(n_model, B))
+    Ye = np.tile(SDSS_SIGMA, (n_model, 1))
+    Ym = np.ones((n_model, B))
+    pick = rs.randint(0, n_model, size=n_obj)
+    X = Y[pick] + SDSS_SIGMA * rs.standard_normal((n_obj, B))
+    Xe = np.tile(SDSS_SIGMA, (n_obj, 1))
+    Xm = np.ones((n_obj, B))
+    z = rs.uniform(0.0, 6.0, n_model)
+    ze = np.full(n_model, 0.05)
+    return Y, Ye, Ym, X, Xe, Xm, z, ze
+
+
+def cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
+    """The oracle (NumPy port of the reference loop) on a bounded sample of the SAME
+    workload: as many objects as fit in ~budget_s seconds against the FULL model set,
+    one process / one core like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import frankenz_oracle as fo
+    kd = fo.KernelDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    yi, ysi = kd.fit(z, ze)
+    n = 0
+    t0 = time.perf_counter()
+    while n < len(X):
+        r = fo.logprob(X[n].copy(), Xe[n].copy(), Xm[n].copy(), Y, Ye, Ym, **kw)
+        fo._pdf_from_lnprob(r[2], z, ze, kd, None, yi, ysi, {})
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * len(Y) / dt, "unit": "evals/s", "pdfs_per_s": n / dt, "cores": 1,
+            "kind": "port",
+            "sample": "%d objects x %d models (full model set), %.1f s, oracle/frankenz_oracle.py "
+                      "logprob+logsumexp+gauss_kde_dict loop" % (n, len(Y), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nobj", type=int, default=1000000, help="objects per GPU per step")
+    ap.add_argument("--nmodel", type=int, default=100000)
+    ap.add_argument("--mode", choices=sorted(MODES), default="A")
+    ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of PDF shards")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from frankenz_amd import PDFDict
+    from frankenz_amd.engine import Engine, kde_opts, like_opts
+
+    kw = MODES[args.mode]
+    N, M = args.nobj, args.nmodel
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank)
+    pd = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    G = pd.Ngrid
+
+    eng = Engine(local)
+    eng.upload_models(Y, Ye, Ym)
+    eng.set_labels(z, ze, label_dict=pd)
+    dev = torch.device("cuda", local)
+    dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
+    d_pdf = torch.empty((N, G), dtype=torch.float64, device=dev)
+    d_lm = torch.empty(N, dtype=torch.float64, device=dev)
+    d_le = torch.empty(N, dtype=torch.float64, device=dev)
+    gathered = None
+    if args.gather and world > 1:
+        gathered = torch.empty((world * N, G), dtype=torch.float64, device=dev)
+    opts, ko = like_opts(kw), kde_opts({})
+
+    def step():
+        eng.fit_predict(dX, dXe, dXm, opts, ko, d_pdf, d_lm, d_le, n=N)
+        if gathered is not None:
+            eng.sync()
+            dist.all_gather_into_tensor(gathered, d_pdf)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = eng.timing()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: PDFs are normalised
+    s = d_pdf[: min(N, 4096)].sum(dim=1)
+    ok = bool(torch.isfinite(s).all().item()) and float((s - 1).abs().max().item()) < 1e-9
+
+    if rank == 0:
+        evals = float(world) * N * M * args.steps
+        value = evals / dt
+        # dominant kernel, HIP events on the library's own stream (per launch)
+        fam = "stats" if tm["ms_stats"] >= tm["ms_kde"] else "kde"
+        ms_launch = tm["ms_" + fam] / max(tm["n_" + fam], 1)
+        launches_per_step = max(tm["n_" + fam], 1) / args.steps
+        evals_per_launch = N * M / launches_per_step
+        ach = evals_per_launch * FLOPS_PASS[args.mode] / (ms_launch * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "object-template likelihood evals/sec (fused fit_predict -> PDFs)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x 5 bands per GPU, "
+                                   "BruteForce.fit_predict(save_fits=False), likelihood mode %s, "
+                                   "dict KDE on 701-pt grid" % (N, M, args.mode),
+                       "n_obj_per_gpu": N, "n_model": M, "n_band": 5, "mode": args.mode,
+                       "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None)},
+            "pdfs_per_s": float(world) * N * args.steps / dt,
+            "pdfs_normalised": ok,
+            "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in
+                                   ("stats", "kde", "planes", "modec", "other")},
+            "roofline": {"bound": "valu_fp64", "kernel": "k_" + fam, "achieved": ach,
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "flops_per_eval": FLOPS_PASS[args.mode],
+                         "avg_launch_ms": ms_launch,
+                         "fused_frac": (N * M * args.steps * FLOPS_FUSED[args.mode]
+                                        / ((tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
+                                        / FP64_VALU_PEAK_TFLOPS)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, args.cpu_seconds)
+            out["speedup_vs_cpu_core"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

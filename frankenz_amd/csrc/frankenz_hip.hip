@@ -67,7 +67,7 @@ struct fz_ctx {
     // models
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
     bool models_masked = false;
-    DevBuf d_y, d_ye2, d_mbits, d_lgA, d_lgB;
+    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB;
     // kde dictionary
     int64_t G = 0, D = 0;
     std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
@@ -135,7 +135,7 @@ extern "C" void fz_ctx_destroy(fz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->d_y, &c->d_ye2, &c->d_mbits, &c->d_lgA, &c->d_lgB, &c->d_widths, &c->d_offsets,
+    DevBuf* all[] = {&c->d_y, &c->d_ye2, &c->d_ye, &c->d_mbits, &c->d_lgA, &c->d_lgB, &c->d_widths, &c->d_offsets,
                      &c->d_kern, &c->d_pos, &c->d_cls, &c->d_norm, &c->d_ly, &c->d_lstd, &c->d_lo, &c->d_hi,
                      &c->d_grid, &c->d_rx, &c->d_rxe, &c->d_rxm, &c->d_ox, &c->d_ov, &c->d_oxw, &c->d_obits,
                      &c->d_oslv, &c->d_flags, &c->d_lmap, &c->d_levid, &c->d_pdfs, &c->d_pl[0], &c->d_pl[1],
@@ -183,22 +183,23 @@ static int copy_out(fz_ctx* c, void* dst, const void* src_dev, size_t bytes) {
 // ---------------------------------------------------------------------------
 // flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1
 __global__ void k_prep_models(const double* y, const double* ye, const double* ym, int64_t M, int64_t Mp,
-                              int B, int BT, double* sy, double* sye2, uint32_t* bits, int* flags) {
+                              int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Mp) return;
     uint32_t bt = 0; int fl = 0;
     for (int b = 0; b < BT; ++b) {
-        double vy = 0.0, ve2 = 0.0;
+        double vy = 0.0, ve2 = 0.0, ve = 0.0;
         if (j < M && b < B) {
             vy = y[j * B + b];
             const double e = ye[j * B + b];
-            ve2 = e * e;
+            ve2 = e * e; ve = e;
             const double mk = ym[j * B + b];
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
-        } else if (j >= M) { vy = 1.0; ve2 = 1.0; }
+        } else if (j >= M) { vy = 1.0; ve2 = 1.0; ve = 1.0; }
         sy[(int64_t)b * Mp + j] = vy;
         sye2[(int64_t)b * Mp + j] = ve2;
+        sye[(int64_t)b * Mp + j] = ve;
     }
     bits[j] = bt;
     if (fl) atomicOr(flags, fl);
@@ -216,14 +217,14 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     const size_t raw = (size_t)M * B * sizeof(double);
     FZCHK(c->d_rx.ensure(raw)); FZCHK(c->d_rxe.ensure(raw)); FZCHK(c->d_rxm.ensure(raw));
     FZCHK(copy_in(c, c->d_rx.p, y, raw)); FZCHK(copy_in(c, c->d_rxe.p, ye, raw)); FZCHK(copy_in(c, c->d_rxm.p, ym, raw));
-    FZCHK(c->d_y.ensure((size_t)BT * Mp * 8)); FZCHK(c->d_ye2.ensure((size_t)BT * Mp * 8));
+    FZCHK(c->d_y.ensure((size_t)BT * Mp * 8)); FZCHK(c->d_ye2.ensure((size_t)BT * Mp * 8)); FZCHK(c->d_ye.ensure((size_t)BT * Mp * 8));
     FZCHK(c->d_mbits.ensure((size_t)Mp * 4)); FZCHK(c->d_flags.ensure(64));
     HIPCHK(hipMemsetAsync(c->d_flags.p, 0, 64, c->stream));
     {
         Timer t(c, &c->tm.ms_other, &c->tm.n_other);
         hipLaunchKernelGGL(k_prep_models, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_rx.as<double>(), c->d_rxe.as<double>(), c->d_rxm.as<double>(), M, Mp, (int)B, BT,
-                           c->d_y.as<double>(), c->d_ye2.as<double>(), c->d_mbits.as<uint32_t>(), c->d_flags.as<int>());
+                           c->d_y.as<double>(), c->d_ye2.as<double>(), c->d_ye.as<double>(), c->d_mbits.as<uint32_t>(), c->d_flags.as<int>());
     }
     HIPCHK(hipGetLastError());
     int fl = 0;
@@ -451,7 +452,7 @@ extern "C" int fz_clean(fz_ctx* c, double* x, double* xe, double* xm, int64_t N,
 // dispatch helpers
 // ---------------------------------------------------------------------------
 static ModelView model_view(fz_ctx* c) {
-    ModelView v; v.y = c->d_y.as<double>(); v.ye2 = c->d_ye2.as<double>(); v.bits = c->d_mbits.as<uint32_t>();
+    ModelView v; v.y = c->d_y.as<double>(); v.ye2 = c->d_ye2.as<double>(); v.ye = c->d_ye.as<double>(); v.bits = c->d_mbits.as<uint32_t>();
     v.M = c->M; v.Mp = c->Mp; return v;
 }
 static ObjView obj_view(fz_ctx* c) {

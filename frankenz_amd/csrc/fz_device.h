@@ -22,6 +22,7 @@ namespace fz {
 struct ModelView {
     const double* y;       // [BT][Mp]  model flux
     const double* ye2;     // [BT][Mp]  model error squared
+    const double* ye;      // [BT][Mp]  model error (mode C squares scale*ye, pdf.py:201-202)
     const uint32_t* bits;  // [Mp]      bit b = models_mask[j][b] != 0 (pad bands 0)
     int64_t M, Mp;
 };

@@ -7,7 +7,9 @@
 // shape) of a chunk of objects is kept in (Nc,M) planes in HBM and one kernel
 // launch advances every still-active object by one iteration; a tiny kernel then
 // applies the stop rule per object.  Objects that have stopped are frozen, which
-// reproduces the reference's per-object iteration count exactly.
+// reproduces the reference's per-object iteration count exactly.  The solve keeps
+// NumPy's operation order (the library is built with -ffp-contract=off) so that the
+// iterates, and therefore the stop decision, track the reference to the last ulps.
 #pragma once
 #include "fz_device.h"
 
@@ -44,8 +46,8 @@ struct ModeC {
             y[b] = mv.y[(int64_t)b * mv.Mp + j];
             x[b] = ov.x[i * BT + b];
             tm[b] = MASKED ? (((jb >> b) & 1u) ? 1.0 : 0.0) : 1.0;
-            double ye2 = mv.ye2[(int64_t)b * mv.Mp + j];
-            var[b] = ov.v[i * BT + b] + (sprev * sprev) * ye2;      // xe^2 + (s*ye)^2
+            const double sye = sprev * mv.ye[(int64_t)b * mv.Mp + j];
+            var[b] = ov.v[i * BT + b] + sye * sye;                  // xe^2 + (s*ye)^2
             inter += tm[b] * y[b] * x[b] / var[b];
             shape += tm[b] * (y[b] * y[b]) / var[b];
             if (b < nband) slog += log(var[b]);                     // unmasked, pdf.py:193-194

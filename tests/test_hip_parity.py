@@ -36,7 +36,16 @@ def test_g1_loglike_golden(mi):
                              ignore_model_err=ime, dim_prior=dp, return_scale=fs)
             key = 'm%d_o%d_%s' % (mi, oi, mk)
             tol = dict(rtol=1e-7, atol=1e-9) if (fs and not ime) else dict(rtol=TIGHT, atol=1e-10)
-            close(res[0], g[key + '_lnl'], **tol)
+            want = g[key + '_lnl']
+            ok = np.ones(len(want), dtype=bool)
+            if fs and dp:
+                # free scale + dim prior with exactly ONE usable band: chi2 is 0 up to
+                # rounding and a = 0, so the reference itself returns nan (chi2 == 0) or
+                # -inf (chi2 ~ 1e-32) by rounding luck (x - s*y == 0 in ~54% of cases).
+                # Both sides must be non-finite there; the value is not defined.
+                ok = np.asarray(g[key + '_ndim']) != 1
+                assert not np.isfinite(res[0][~ok]).any() and not np.isfinite(want[~ok]).any()
+            close(res[0][ok], want[ok], **tol)
             np.testing.assert_array_equal(res[1], g[key + '_ndim'])
             assert res[1].dtype == g[key + '_ndim'].dtype
             close(res[2], g[key + '_chi2'], **tol)
@@ -209,7 +218,17 @@ def test_oracle_parity_band_counts(B, kw):
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
     rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
-    close(bf.fit_lnlike, rf['lnlike'], rtol=TIGHT, atol=1e-9)
-    close(bf.fit_chi2, rf['chi2'], rtol=TIGHT, atol=1e-9)
     np.testing.assert_array_equal(bf.fit_Ndim, rf['Ndim'])
-    close(p, rp, rtol=1e-8, atol=1e-13); close(lm, rlm); close(le, rle)
+    close(bf.fit_chi2, rf['chi2'], rtol=TIGHT, atol=1e-9)
+    defined = np.ones_like(rf['lnlike'], dtype=bool)
+    if kw.get('free_scale') and kw.get('dim_prior', True):
+        # one usable band + free scale: nan or -inf by rounding luck in the reference
+        defined = rf['Ndim'] != 1
+        assert not np.isfinite(bf.fit_lnlike[~defined]).any()
+        assert not np.isfinite(rf['lnlike'][~defined]).any()
+    close(bf.fit_lnlike[defined], rf['lnlike'][defined], rtol=TIGHT, atol=1e-9)
+    # objects whose row holds a nan on either side have an all-nan PDF on that side
+    rows = ~(np.isnan(bf.fit_lnlike).any(axis=1) | np.isnan(rf['lnlike']).any(axis=1))
+    assert rows.sum() >= 1 and np.isnan(rp[np.isnan(rf['lnlike']).any(axis=1)]).all()
+    assert np.isnan(p[np.isnan(bf.fit_lnlike).any(axis=1)]).all()
+    close(p[rows], rp[rows], rtol=1e-8, atol=1e-13); close(lm[rows], rlm[rows]); close(le[rows], rle[rows])
