@@ -208,9 +208,11 @@ def test_oracle_parity_band_counts(B, kw):
     M, N = 700, 37
     sig = rs.uniform(0.3, 3.0, B)
     Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.05 * Y * rs.uniform(0.5, 2, size=(M, B))
-    Ym = (rs.rand(M, B) > 0.05).astype(float)
+    # at most one masked band per model / per object, so Ndim >= B-2 >= 1
+    Ym = np.ones((M, B)); hit = rs.rand(M) < 0.15; Ym[hit, rs.randint(0, B, hit.sum())] = 0
     X = Y[rs.choice(M, N)] * rs.lognormal(0, .3, N)[:, None] + sig * rs.randn(N, B)
-    Xe = np.tile(sig, (N, 1)); Xm = (rs.rand(N, B) > 0.05).astype(float)
+    Xe = np.tile(sig, (N, 1))
+    Xm = np.ones((N, B)); hit = rs.rand(N) < 0.3; Xm[hit, rs.randint(0, B, hit.sum())] = 0
     z = rs.uniform(0, 6, M); ze = rs.uniform(0.01, 0.2, M)
     bf = BruteForce(Y, Ye, Ym)
     p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
