@@ -162,11 +162,12 @@ def main():
         evals = float(world) * N * M * args.steps
         value = evals / dt
         # dominant kernel, HIP events on the library's own stream (per launch)
-        fam = "stats" if tm["ms_stats"] >= tm["ms_kde"] else "kde"
+        fam = max(("fused", "stats", "kde"), key=lambda k: tm["ms_" + k])
         ms_launch = tm["ms_" + fam] / max(tm["n_" + fam], 1)
         launches_per_step = max(tm["n_" + fam], 1) / args.steps
         evals_per_launch = N * M / launches_per_step
-        ach = evals_per_launch * FLOPS_PASS[args.mode] / (ms_launch * 1e-3) / 1e12
+        flops_eval = FLOPS_FUSED[args.mode] if fam == "fused" else FLOPS_PASS[args.mode]
+        ach = evals_per_launch * flops_eval / (ms_launch * 1e-3) / 1e12
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
@@ -188,14 +189,14 @@ def main():
             "pdfs_per_s": float(world) * N * args.steps / dt,
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in
-                                   ("stats", "kde", "planes", "modec", "other")},
+                                   ("fused", "stats", "kde", "planes", "modec", "other")},
             "roofline": {"bound": "valu_fp64", "kernel": "k_" + fam, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "flops_per_eval": FLOPS_PASS[args.mode],
+                         "flops_per_eval": flops_eval,
                          "avg_launch_ms": ms_launch,
                          "fused_frac": (N * M * args.steps * FLOPS_FUSED[args.mode]
-                                        / ((tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
+                                        / ((tm["ms_fused"] + tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
                                         / FP64_VALU_PEAK_TFLOPS)},
         }
         if world == 1 and not args.no_cpu:

@@ -23,6 +23,7 @@ class KdeOpts(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("ms_planes", C.c_double), ("n_planes", C.c_int64),
+                ("ms_fused", C.c_double), ("n_fused", C.c_int64),
                 ("ms_stats", C.c_double), ("n_stats", C.c_int64),
                 ("ms_kde", C.c_double), ("n_kde", C.c_int64),
                 ("ms_modec", C.c_double), ("n_modec", C.c_int64),
@@ -54,6 +55,7 @@ ABI = {
     "fz_predict_logwt": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_knn_upload_trees": (C.c_int, [_P, _P, _I32, _I64, _I32]),
     "fz_knn_query": (C.c_int, [_P, _P, _I64, _I32, _F64, _P]),
+    "fz_selftest_math": (C.c_int, [_P, _I32, _P, _I64, _P]),
     "fz_knn_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
                                      C.POINTER(KdeOpts)] + [_P] * 10),
 }

@@ -1,110 +1,17 @@
 // libfrankenz_hip.so -- C ABI (include/frankenz_hip.h) over the gfx950 kernels.
-#include "../../include/frankenz_hip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
+// This translation unit: context, uploads, object preparation, the ABI entry points
+// and the kernels that do not depend on the band count.  The photometric kernels
+// are instantiated per band count in fz_inst.hip.
+#include "fz_ctx.h"
 #include "fz_kernels.h"
 #include "fz_knn.h"
+#include "fz_launch.h"
 #include "fz_modec.h"
 
 using namespace fz;
 
-// ---------------------------------------------------------------------------
-// errors
-// ---------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g_err = buf;
-    return code;
-}
-#define HIPCHK(call)                                                                      \
-    do {                                                                                  \
-        hipError_t e_ = (call);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return fail(-1, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define FZCHK(call) do { int r_ = (call); if (r_ != 0) return r_; } while (0)
-
-extern "C" const char* fz_last_error(void) { return g_err.c_str(); }
-
-// ---------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------
-struct DevBuf {            // grow-only cached device allocation
-    void* p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return fail(-2, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        cap = bytes;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() const { return (T*)p; }
-};
-
-struct fz_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    fz_timing tm{};
-    int64_t ws_limit = (int64_t)8 << 30;
-    int cu_count = 256;
-    int lds_per_block = 65536;
-
-    // models
-    int64_t M = 0, Mp = 0; int B = 0, BT = 0;
-    bool models_masked = false;
-    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB;
-    // kde dictionary
-    int64_t G = 0, D = 0;
-    std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
-    DevBuf d_widths, d_offsets, d_kern;
-    // labels
-    int label_mode = 0;        // 0 none, 1 dict, 2 grid
-    int64_t label_M = 0;
-    bool single_cls = false; int32_t cls0 = 0, w0 = 0;
-    DevBuf d_pos, d_cls, d_norm, d_ly, d_lstd, d_lo, d_hi, d_grid;
-    // per-chunk object buffers
-    DevBuf d_rx, d_rxe, d_rxm, d_ox, d_ov, d_oxw, d_obits, d_oslv, d_flags;
-    DevBuf d_lmap, d_levid, d_pdfs;
-    DevBuf d_pl[5];            // staging planes
-    DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt;
-    // knn
-    int knn_K = 0, knn_F = 0; int64_t knn_M = 0;
-    DevBuf d_trees, d_q, d_idx, d_nbr, d_nn;
-};
-
-static bool is_device_ptr(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t a;
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
-}
-
-struct Timer {     // HIP-event bracket on the ctx stream, accumulated per kernel family
-    fz_ctx* c; double* ms; int64_t* n;
-    Timer(fz_ctx* c_, double* ms_, int64_t* n_) : c(c_), ms(ms_), n(n_) { (void)hipEventRecord(c->ev0, c->stream); }
-    ~Timer() {
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
-        float t = 0; (void)hipEventElapsedTime(&t, c->ev0, c->ev1);
-        *ms += t; *n += 1;
-    }
-};
+std::string& fz_err_slot() { static thread_local std::string e; return e; }
+extern "C" const char* fz_last_error(void) { return fz_err_slot().c_str(); }
 
 extern "C" int fz_device_count(void) {
     int n = 0;
@@ -126,7 +33,6 @@ extern "C" int fz_ctx_create(int device, fz_ctx** out) {
     hipDeviceProp_t pr;
     HIPCHK(hipGetDeviceProperties(&pr, device));
     c->cu_count = pr.multiProcessorCount;
-    c->lds_per_block = (int)pr.sharedMemPerBlock;
     *out = c;
     return 0;
 }
@@ -135,14 +41,7 @@ extern "C" void fz_ctx_destroy(fz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->d_y, &c->d_ye2, &c->d_ye, &c->d_mbits, &c->d_lgA, &c->d_lgB, &c->d_widths, &c->d_offsets,
-                     &c->d_kern, &c->d_pos, &c->d_cls, &c->d_norm, &c->d_ly, &c->d_lstd, &c->d_lo, &c->d_hi,
-                     &c->d_grid, &c->d_rx, &c->d_rxe, &c->d_rxm, &c->d_ox, &c->d_ov, &c->d_oxw, &c->d_obits,
-                     &c->d_oslv, &c->d_flags, &c->d_lmap, &c->d_levid, &c->d_pdfs, &c->d_pl[0], &c->d_pl[1],
-                     &c->d_pl[2], &c->d_pl[3], &c->d_pl[4], &c->d_mc[0], &c->d_mc[1], &c->d_mc[2], &c->d_mc[3],
-                     &c->d_mcerr, &c->d_mcfn, &c->d_mcact, &c->d_mccnt, &c->d_trees, &c->d_q, &c->d_idx,
-                     &c->d_nbr, &c->d_nn};
-    for (DevBuf* b : all) b->release();
+    for (DevBuf* b : c->all_bufs()) b->release();
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -164,24 +63,11 @@ extern "C" int fz_set_workspace_limit(fz_ctx* c, int64_t bytes) {
     c->ws_limit = bytes; return 0;
 }
 
-// copy helpers (host or device on either side), ordered on the ctx stream
-static int copy_in(fz_ctx* c, void* dst_dev, const void* src, size_t bytes) {
-    if (!bytes) return 0;
-    HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-static int copy_out(fz_ctx* c, void* dst, const void* src_dev, size_t bytes) {
-    if (!bytes) return 0;
-    HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
 // ---------------------------------------------------------------------------
 // models  (BruteForce.__init__, bruteforce.py:36-64)
 // ---------------------------------------------------------------------------
-// flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1
+// flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1,
+// bit2 = some value is outside the range the reciprocal-based fast arithmetic accepts
 __global__ void k_prep_models(const double* y, const double* ye, const double* ym, int64_t M, int64_t Mp,
                               int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,6 +82,7 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
             const double mk = ym[j * B + b];
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
+            if (!(ve2 == 0.0 || (ve2 > 1e-50 && ve2 < 1e50)) || !(fabs(vy) < 1e100)) fl |= 4;
         } else if (j >= M) { vy = 1.0; ve2 = 1.0; ve = 1.0; }
         sy[(int64_t)b * Mp + j] = vy;
         sye2[(int64_t)b * Mp + j] = ve2;
@@ -232,6 +119,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     if (fl & 2) return fail(-4, "models_mask must be binary (0/1)");
     c->M = M; c->Mp = Mp; c->B = B; c->BT = BT;
     c->models_masked = (fl & 1) || (BT != B);
+    c->models_wild = (fl & 4) != 0;
     // gammaln(a) + a ln2 tables: a = n/2 (pdf.py:91-93) and a = (n-1)/2 (pdf.py:227-229)
     std::vector<double> ta(BT + 1), tb(BT + 1);
     for (int n = 0; n <= BT; ++n) {
@@ -371,16 +259,17 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
 // ---------------------------------------------------------------------------
 // objects: clean (pdf.py:309-311) + per-chunk derived arrays
 // ---------------------------------------------------------------------------
-// vmode 0: v = xe^2 (modes A, C) ; 1: v = 1/xe^2, xw = x/xe^2 (modes Ai, B)
-// flags: bit0 some data mask is 0 after cleaning, bit1 some mask non-binary
+// vmode 0: v = xe^2 (modes A, C) ; 1: v = 1/xe^2 (modes Ai, B)
+// flags: bit0 some data mask is 0 after cleaning, bit1 some mask non-binary,
+// bit2 some value outside the fast arithmetic's range
 __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int B, int BT, int vmode,
-                               int derive, double* ox, double* ov, double* oxw, uint32_t* bits, double* slv,
+                               int derive, double* ox, double* ov, uint32_t* bits, double* slv,
                                int* flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     uint32_t bt = 0; int fl = 0; double sl = 0.0;
     for (int b = 0; b < BT; ++b) {
-        double fx = 0.0, v = 1.0, fw = 0.0;
+        double fx = 0.0, v = 1.0;
         if (b < B) {
             double f = x[i * B + b], e = xe[i * B + b], mk = xm[i * B + b];
             const bool clean = (f - f == 0.0) && (e - e == 0.0) && (e > 0.0);   // isfinite & isfinite & >0
@@ -388,11 +277,12 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
             const double e2 = e * e;
+            if (!(e2 > 1e-50 && e2 < 1e50) || !(fabs(f) < 1e100)) fl |= 4;
             sl += log(e2);
             fx = f;
-            if (vmode == 0) v = e2; else { v = 1.0 / e2; fw = f / e2; }
+            v = (vmode == 0) ? e2 : 1.0 / e2;
         }
-        if (derive) { ox[i * BT + b] = fx; ov[i * BT + b] = v; oxw[i * BT + b] = fw; }
+        if (derive) { ox[i * BT + b] = fx; ov[i * BT + b] = v; }
     }
     if (derive) { bits[i] = bt; slv[i] = sl; }
     if (fl) atomicOr(flags, fl);
@@ -415,7 +305,7 @@ static int prep_chunk(fz_ctx* c, double* x, double* xe, double* xm, int64_t i0, 
     }
     if (derive) {
         const size_t d = (size_t)n * BT * 8;
-        FZCHK(c->d_ox.ensure(d)); FZCHK(c->d_ov.ensure(d)); FZCHK(c->d_oxw.ensure(d));
+        FZCHK(c->d_ox.ensure(d)); FZCHK(c->d_ov.ensure(d));
         FZCHK(c->d_obits.ensure((size_t)n * 4)); FZCHK(c->d_oslv.ensure((size_t)n * 8));
     }
     FZCHK(c->d_flags.ensure(64));
@@ -423,7 +313,7 @@ static int prep_chunk(fz_ctx* c, double* x, double* xe, double* xm, int64_t i0, 
     {
         Timer t(c, &c->tm.ms_other, &c->tm.n_other);
         hipLaunchKernelGGL(k_prep_objects, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ch.x, ch.xe, ch.xm,
-                           n, B, BT, vmode, derive ? 1 : 0, c->d_ox.as<double>(), c->d_ov.as<double>(), c->d_oxw.as<double>(),
+                           n, B, BT, vmode, derive ? 1 : 0, c->d_ox.as<double>(), c->d_ov.as<double>(),
                            c->d_obits.as<uint32_t>(), c->d_oslv.as<double>(), c->d_flags.as<int>());
     }
     HIPCHK(hipGetLastError());
@@ -449,109 +339,30 @@ extern "C" int fz_clean(fz_ctx* c, double* x, double* xe, double* xm, int64_t N,
 }
 
 // ---------------------------------------------------------------------------
-// dispatch helpers
+// dispatch on the band-count template (one translation unit each, fz_inst.hip)
 // ---------------------------------------------------------------------------
-static ModelView model_view(fz_ctx* c) {
-    ModelView v; v.y = c->d_y.as<double>(); v.ye2 = c->d_ye2.as<double>(); v.ye = c->d_ye.as<double>(); v.bits = c->d_mbits.as<uint32_t>();
-    v.M = c->M; v.Mp = c->Mp; return v;
-}
-static ObjView obj_view(fz_ctx* c) {
-    ObjView v; v.x = c->d_ox.as<double>(); v.v = c->d_ov.as<double>(); v.xw = c->d_oxw.as<double>();
-    v.bits = c->d_obits.as<uint32_t>(); v.slv = c->d_oslv.as<double>(); return v;
-}
-static LikeParams like_params(fz_ctx* c, int mode, int dim_prior) {
-    LikeParams lp; lp.dim_prior = dim_prior; lp.nband = c->B;
-    lp.lgtab = (mode == 2) ? c->d_lgB.as<double>() : c->d_lgA.as<double>();
-    const double a = (mode == 2) ? 0.5 * (c->B - 1) : 0.5 * c->B;
-    lp.lg_full = std::lgamma(a) + a * FZ_LN2;
-    return lp;
-}
-static int like_mode(const fz_like_opts* o) {      // 0 A, 1 Ai, 2 B, 3 C
-    if (!o->free_scale) return o->ignore_model_err ? 1 : 0;
-    return o->ignore_model_err ? 2 : 3;
-}
-
-// instantiate F<BT,MODE,MASKED> for the runtime triple
-#define FZ_DISPATCH(BT_, MODE_, MASKED_, CALL)                                                    \
-    do {                                                                                          \
-        const int key_ = ((BT_) == 5 ? 0 : ((BT_) == 8 ? 1 : 2)) * 6 + (MODE_) * 2 + ((MASKED_) ? 1 : 0); \
-        switch (key_) {                                                                           \
-            case 0: { CALL(5, 0, false); } break;   case 1: { CALL(5, 0, true); } break;           \
-            case 2: { CALL(5, 1, false); } break;   case 3: { CALL(5, 1, true); } break;           \
-            case 4: { CALL(5, 2, false); } break;   case 5: { CALL(5, 2, true); } break;           \
-            case 7: { CALL(8, 0, true); } break;    case 9: { CALL(8, 1, true); } break;           \
-            case 11: { CALL(8, 2, true); } break;   case 13: { CALL(16, 0, true); } break;         \
-            case 15: { CALL(16, 1, true); } break;  case 17: { CALL(16, 2, true); } break;         \
-            default: return fail(-1, "internal: no kernel for BT=%d mode=%d masked=%d", (BT_), (MODE_), (int)(MASKED_)); \
-        }                                                                                         \
-    } while (0)
-
-template <class SRC>
-static int launch_stats(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, double* lmap, double* levid) {
-    constexpr int TW = 4, WPB = 4;
-    const int64_t per = TW * WPB;
-    Timer t(c, &c->tm.ms_stats, &c->tm.n_stats);
-    hipLaunchKernelGGL((k_stats<SRC, TW>), dim3((unsigned)((n + per - 1) / per)), dim3(WPB * 64), 0, c->stream, src, n, M,
-                       linear, lmap, levid);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-static int kde_view(fz_ctx* c, KdeView& kv, int& kmode) {
-    if (c->label_mode == 0) return fail(-1, "labels have not been uploaded");
-    if (c->label_M != c->M && c->knn_M == 0) return fail(-1, "labels (%lld) do not match the model count (%lld)", (long long)c->label_M, (long long)c->M);
-    memset(&kv, 0, sizeof kv);
-    kv.G = c->G;
-    kv.norm = c->d_norm.as<double>();
-    if (c->label_mode == 1) {
-        kv.pos = c->d_pos.as<int32_t>(); kv.cls = c->d_cls.as<int32_t>();
-        kv.widths = c->d_widths.as<int64_t>(); kv.offsets = c->d_offsets.as<int64_t>(); kv.kern = c->d_kern.as<double>();
-        kv.w0 = c->w0; kv.koff0 = c->h_offsets[c->cls0];
-        kmode = c->single_cls ? KDE_HIST : KDE_DICT;
-        kv.acc_stride = (int)(kmode == KDE_HIST ? c->G + 2 * c->w0 : c->G);
-    } else {
-        kv.ly = c->d_ly.as<double>(); kv.lstd = c->d_lstd.as<double>(); kv.lo = c->d_lo.as<int32_t>(); kv.hi = c->d_hi.as<int32_t>();
-        kv.grid = c->d_grid.as<double>();
-        kmode = KDE_GRID; kv.acc_stride = (int)c->G;
+static int run_planes(fz_ctx* c, int mode, int var, int dp, int64_t n, double* lnl, double* chi2, int64_t* ndim,
+                      double* scale, double* serr) {
+    switch (c->BT) {
+        case 5: return fz_planes_bt5(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        case 8: return fz_planes_bt8(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        default: return fz_planes_bt16(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
     }
-    return 0;
 }
-
-template <class SRC, int TW, int KMODE>
-static int launch_kde_tw(fz_ctx* c, const SRC& src, const KdeView& kv, int wpb, int64_t n, int64_t M, int linear,
-                         const double* lmap, const double* levid, const fz_kde_opts* ko, double* pdfs) {
-    const int64_t per = (int64_t)TW * wpb;
-    const size_t lds = (size_t)wpb * TW * kv.acc_stride * 8;
-    auto kern = k_kde<SRC, TW, KMODE>;
-    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    Timer t(c, &c->tm.ms_kde, &c->tm.n_kde);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((n + per - 1) / per)), dim3(wpb * 64), lds, c->stream, src, kv, n, M, linear,
-                       lmap, levid, ko->wt_thresh, ko->normalize, pdfs);
-    HIPCHK(hipGetLastError());
-    return 0;
+static int run_fitpredict(fz_ctx* c, int mode, int var, int dp, int64_t n, const fz_kde_opts* ko, double* lmap, double* levid,
+                          double* pdfs) {
+    switch (c->BT) {
+        case 5: return fz_fitpredict_bt5(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        case 8: return fz_fitpredict_bt8(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        default: return fz_fitpredict_bt16(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+    }
 }
-
-template <class SRC, int KMODE>
-static int launch_kde_k(fz_ctx* c, const SRC& src, const KdeView& kv, int64_t n, int64_t M, int linear, const double* lmap,
-                        const double* levid, const fz_kde_opts* ko, double* pdfs) {
-    // objects per wave / waves per block from the LDS each object's accumulator needs
-    const size_t per_obj = (size_t)kv.acc_stride * 8;
-    const size_t budget = 160 * 1024;
-    if (per_obj > budget) return fail(-5, "PDF grid of %lld points needs %zu B of LDS per object (> 160 KiB)", (long long)kv.G, per_obj);
-    if (per_obj * 8 <= 53 * 1024) return launch_kde_tw<SRC, 2, KMODE>(c, src, kv, 4, n, M, linear, lmap, levid, ko, pdfs);
-    if (per_obj * 4 <= budget) return launch_kde_tw<SRC, 1, KMODE>(c, src, kv, 4, n, M, linear, lmap, levid, ko, pdfs);
-    if (per_obj * 2 <= budget) return launch_kde_tw<SRC, 1, KMODE>(c, src, kv, 2, n, M, linear, lmap, levid, ko, pdfs);
-    return launch_kde_tw<SRC, 1, KMODE>(c, src, kv, 1, n, M, linear, lmap, levid, ko, pdfs);
-}
-
-template <class SRC>
-static int launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, const double* lmap, const double* levid,
-                      const fz_kde_opts* ko, double* pdfs) {
-    KdeView kv; int kmode = 0;
-    FZCHK(kde_view(c, kv, kmode));
-    if (kmode == KDE_HIST) return launch_kde_k<SRC, KDE_HIST>(c, src, kv, n, M, linear, lmap, levid, ko, pdfs);
-    if (kmode == KDE_DICT) return launch_kde_k<SRC, KDE_DICT>(c, src, kv, n, M, linear, lmap, levid, ko, pdfs);
-    return launch_kde_k<SRC, KDE_GRID>(c, src, kv, n, M, linear, lmap, levid, ko, pdfs);
+static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o) {
+    switch (c->BT) {
+        case 5: return fz_modec_bt5(c, var, n, o);
+        case 8: return fz_modec_bt8(c, var, n, o);
+        default: return fz_modec_bt16(c, var, n, o);
+    }
 }
 
 static int check_kde_opts(const fz_kde_opts* ko) {
@@ -560,50 +371,6 @@ static int check_kde_opts(const fz_kde_opts* ko) {
         return fail(-6, "wt_thresh=None selects the reference's CDF thresholding (pdf.py:513-516 / 593-597), "
                         "which is not implemented on the device");
     return 0;
-}
-
-// ---------------------------------------------------------------------------
-// mode C driver on a prepared chunk: leaves converged state in c->d_mc[*]
-// ---------------------------------------------------------------------------
-template <int BT, bool MASKED>
-static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o) {
-    const int64_t M = c->M;
-    const size_t pl = (size_t)n * M * 8;
-    for (int k = 0; k < 4; ++k) FZCHK(c->d_mc[k].ensure(pl));
-    FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(n * 4)); FZCHK(c->d_mccnt.ensure(64));
-    ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
-    st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.firstnan = c->d_mcfn.as<int>();
-    st.active = c->d_mcact.as<int>(); st.nactive = c->d_mccnt.as<int>();
-    HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
-    HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
-    HIPCHK(hipMemsetAsync(st.active, 0xff, n * 4, c->stream));       // all active (non-zero)
-    ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B;
-    const int64_t tiles = (M + 255) / 256;
-    const int64_t nblk = n * tiles;
-    if (nblk > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
-    const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
-    Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
-    hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 1);
-    int it = 0, nact = 1;
-    while (nact > 0) {
-        if (it >= max_iter)
-            return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
-                            "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
-        HIPCHK(hipMemsetAsync(st.nactive, 0, 4, c->stream));
-        hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 0);
-        hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, st, n, o->ltol);
-        HIPCHK(hipMemcpyAsync(&nact, st.nactive, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        ++it;
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-static int modec_dispatch(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o) {
-    if (c->BT == 5) return masked ? run_modec<5, true>(c, n, o) : run_modec<5, false>(c, n, o);
-    if (c->BT == 8) return run_modec<8, true>(c, n, o);
-    return run_modec<16, true>(c, n, o);
 }
 
 static int modec_final(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o, double* lnl, double* chi2, int64_t* ndim,
@@ -642,7 +409,8 @@ extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, c
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
         FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
-        const bool masked = c->models_masked || (fl & 1);
+        const int var = pick_var(c, fl);
+        const bool masked = var != VAR_FAST;
         void* dst[5];
         for (int k = 0; k < 5; ++k) {
             if (!outs[k]) dst[k] = nullptr;
@@ -650,18 +418,11 @@ extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, c
             else { FZCHK(c->d_pl[k].ensure((size_t)n * row)); dst[k] = c->d_pl[k].p; }
         }
         if (mode == 3) {
-            FZCHK(modec_dispatch(c, n, masked, o));
+            FZCHK(run_modec(c, var, n, o));
             FZCHK(modec_final(c, n, masked, o, (double*)dst[0], (double*)dst[1], (int64_t*)dst[2], (double*)dst[3], (double*)dst[4]));
         } else {
-            constexpr int TO = 16;
-            dim3 grid((unsigned)((n + TO - 1) / TO), (unsigned)((M + 255) / 256));
-            Timer t(c, &c->tm.ms_planes, &c->tm.n_planes);
-#define FZ_CALL_PLANES(BT_, MODE_, MASKED_)                                                              \
-    PhotSrc<BT_, MODE_, MASKED_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, o->dim_prior); \
-    hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, MASKED_>, TO>), grid, dim3(256), 0, c->stream, ph, n, M, \
-                       (double*)dst[0], (double*)dst[1], (int64_t*)dst[2], (double*)dst[3], (double*)dst[4]);
-            FZ_DISPATCH(c->BT, mode, masked, FZ_CALL_PLANES);
-            HIPCHK(hipGetLastError());
+            FZCHK(run_planes(c, mode, var, o->dim_prior, n, (double*)dst[0], (double*)dst[1], (int64_t*)dst[2], (double*)dst[3],
+                             (double*)dst[4]));
         }
         for (int k = 0; k < 5; ++k)
             if (outs[k] && !dev_out[k]) FZCHK(copy_out(c, (char*)outs[k] + (size_t)i0 * row, dst[k], (size_t)n * row));
@@ -690,24 +451,21 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
         FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
-        const bool masked = c->models_masked || (fl & 1);
+        const int var = pick_var(c, fl);
+        const bool masked = var != VAR_FAST;
         double* d_pdf; double* d_lm; double* d_le;
         if (pdf_dev) d_pdf = pdfs + i0 * G; else { FZCHK(c->d_pdfs.ensure((size_t)n * G * 8)); d_pdf = c->d_pdfs.as<double>(); }
         if (lmap && lm_dev) d_lm = lmap + i0; else { FZCHK(c->d_lmap.ensure(n * 8)); d_lm = c->d_lmap.as<double>(); }
         if (levid && le_dev) d_le = levid + i0; else { FZCHK(c->d_levid.ensure(n * 8)); d_le = c->d_levid.as<double>(); }
         if (mode == 3) {
-            FZCHK(modec_dispatch(c, n, masked, o));
+            FZCHK(run_modec(c, var, n, o));
             double* lpl = c->d_mc[1].as<double>();
             FZCHK(modec_final(c, n, masked, o, lpl, nullptr, nullptr, nullptr, nullptr));   // in place: lnl plane
             PlaneSrc ps; ps.p = lpl; ps.ld = M;
-            FZCHK(launch_stats(c, ps, n, M, 0, d_lm, d_le));
-            FZCHK(launch_kde(c, ps, n, M, 0, d_lm, d_le, ko, d_pdf));
+            FZCHK(fz_launch_stats(c, ps, n, M, 0, d_lm, d_le));
+            FZCHK(fz_launch_kde(c, ps, n, M, 0, d_lm, d_le, ko, d_pdf));
         } else {
-#define FZ_CALL_FUSED(BT_, MODE_, MASKED_)                                                               \
-    PhotSrc<BT_, MODE_, MASKED_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, o->dim_prior); \
-    FZCHK(launch_stats(c, ph, n, M, 0, d_lm, d_le));                                                     \
-    FZCHK(launch_kde(c, ph, n, M, 0, d_lm, d_le, ko, d_pdf));
-            FZ_DISPATCH(c->BT, mode, masked, FZ_CALL_FUSED);
+            FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));
         }
         if (!pdf_dev) FZCHK(copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8));
         if (lmap && !lm_dev) FZCHK(copy_out(c, lmap + i0, d_lm, n * 8));
@@ -745,8 +503,8 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
         if (lmap && lm_dev) d_lm = lmap + i0; else { if ((rc = c->d_lmap.ensure(n * 8))) break; d_lm = c->d_lmap.as<double>(); }
         if (levid && le_dev) d_le = levid + i0; else { if ((rc = c->d_levid.ensure(n * 8))) break; d_le = c->d_levid.as<double>(); }
         PlaneSrc ps; ps.p = d_in; ps.ld = M;
-        if ((rc = launch_stats(c, ps, n, M, linear, d_lm, d_le))) break;
-        if ((rc = launch_kde(c, ps, n, M, linear, d_lm, d_le, ko, d_pdf))) break;
+        if ((rc = fz_launch_stats(c, ps, n, M, linear, d_lm, d_le))) break;
+        if ((rc = fz_launch_kde(c, ps, n, M, linear, d_lm, d_le, ko, d_pdf))) break;
         if (!pdf_dev && (rc = copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8))) break;
         if (lmap && !lm_dev && (rc = copy_out(c, lmap + i0, d_lm, n * 8))) break;
         if (levid && !le_dev && is_log && (rc = copy_out(c, levid + i0, d_le, n * 8))) break;

@@ -1,0 +1,164 @@
+// Host-side context shared by the translation units of libfrankenz_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/frankenz_hip.h"
+#include "fz_device.h"
+
+// ---- errors ------------------------------------------------------------------
+std::string& fz_err_slot();                       // thread-local, defined in frankenz_hip.hip
+inline int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    fz_err_slot() = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(-1, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define FZCHK(call) do { int r_ = (call); if (r_ != 0) return r_; } while (0)
+
+// ---- grow-only cached device allocation ----------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(-2, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct fz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    fz_timing tm{};
+    int64_t ws_limit = (int64_t)16 << 30;
+    int cu_count = 256;
+    int force_twopass = 0;     // diagnostics: disable the single-pass fused kernel
+
+    // models (BruteForce.__init__)
+    int64_t M = 0, Mp = 0; int B = 0, BT = 0;
+    bool models_masked = false, models_wild = false;
+    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB;
+    // kde dictionary (PDFDict)
+    int64_t G = 0, D = 0;
+    std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
+    DevBuf d_widths, d_offsets, d_kern;
+    // labels
+    int label_mode = 0;        // 0 none, 1 dict, 2 grid
+    int64_t label_M = 0;
+    bool single_cls = false; int32_t cls0 = 0, w0 = 0;
+    DevBuf d_pos, d_cls, d_norm, d_ly, d_lstd, d_lo, d_hi, d_grid;
+    // per-chunk object buffers
+    DevBuf d_rx, d_rxe, d_rxm, d_ox, d_ov, d_obits, d_oslv, d_flags;
+    DevBuf d_lmap, d_levid, d_pdfs;
+    DevBuf d_pl[5];            // staging planes
+    DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt;
+    DevBuf d_cand;             // candidate lists of the single-pass fused kernel
+    // knn
+    int knn_K = 0, knn_F = 0; int64_t knn_M = 0;
+    DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm;
+
+    std::vector<DevBuf*> all_bufs() {
+        std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
+                                  &d_cls, &d_norm, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
+                                  &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_mcerr,
+                                  &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
+        for (auto& b : d_pl) v.push_back(&b);
+        for (auto& b : d_mc) v.push_back(&b);
+        return v;
+    }
+};
+
+inline bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// HIP-event bracket on the ctx stream, accumulated per kernel family
+struct Timer {
+    fz_ctx* c; double* ms; int64_t* n;
+    Timer(fz_ctx* c_, double* ms_, int64_t* n_) : c(c_), ms(ms_), n(n_) { (void)hipEventRecord(c->ev0, c->stream); }
+    ~Timer() {
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float t = 0; (void)hipEventElapsedTime(&t, c->ev0, c->ev1);
+        *ms += t; *n += 1;
+    }
+};
+
+// copies with either side on host or device, ordered on the ctx stream
+inline int copy_in(fz_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+    if (!bytes) return 0;
+    HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+inline int copy_out(fz_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    if (!bytes) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- device views ------------------------------------------------------------
+inline fz::ModelView model_view(fz_ctx* c) {
+    fz::ModelView v; v.y = c->d_y.as<double>(); v.ye2 = c->d_ye2.as<double>(); v.ye = c->d_ye.as<double>();
+    v.bits = c->d_mbits.as<uint32_t>(); v.M = c->M; v.Mp = c->Mp; return v;
+}
+inline fz::ObjView obj_view(fz_ctx* c) {
+    fz::ObjView v; v.x = c->d_ox.as<double>(); v.v = c->d_ov.as<double>();
+    v.bits = c->d_obits.as<uint32_t>(); v.slv = c->d_oslv.as<double>(); return v;
+}
+inline fz::LikeParams like_params(fz_ctx* c, int mode, int dim_prior) {
+    fz::LikeParams lp; lp.dim_prior = dim_prior; lp.nband = c->B;
+    lp.lgtab = (mode == 2) ? c->d_lgB.as<double>() : c->d_lgA.as<double>();
+    const double a = (mode == 2) ? 0.5 * (c->B - 1) : 0.5 * c->B;
+    lp.lg_full = std::lgamma(a) + a * FZ_LN2;
+    return lp;
+}
+inline int like_mode(const fz_like_opts* o) {      // 0 A, 1 Ai, 2 B, 3 C
+    if (!o->free_scale) return o->ignore_model_err ? 1 : 0;
+    return o->ignore_model_err ? 2 : 3;
+}
+// arithmetic variant of a chunk: see VAR_* in fz_device.h
+inline int pick_var(fz_ctx* c, int obj_flags) {
+    if (c->models_wild || (obj_flags & 4)) return fz::VAR_SAFE;
+    if (c->models_masked || (obj_flags & 1)) return fz::VAR_MASKED;
+    return fz::VAR_FAST;
+}
+
+// ---- per-band-count launchers (fz_inst.hip, one translation unit per BT) ------
+struct FzKdeArgs;   // fz_launch.h
+#define FZ_DECL_BT(N)                                                                                     \
+    int fz_planes_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, double* lnl, double* chi2, \
+                        int64_t* ndim, double* scale, double* serr);                                      \
+    int fz_fitpredict_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const fz_kde_opts* ko, \
+                            double* lmap, double* levid, double* pdfs);                                   \
+    int fz_modec_bt##N(fz_ctx* c, int var, int64_t n, const fz_like_opts* o);
+FZ_DECL_BT(5)
+FZ_DECL_BT(8)
+FZ_DECL_BT(16)
+#undef FZ_DECL_BT

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fz_fastmath.h"
+
 #define FZ_WAVE 64
 #define FZ_LN2PI 1.8378770664093453   // log(2*pi)
 #define FZ_LN2 0.6931471805599453
@@ -17,7 +19,7 @@
 namespace fz {
 
 // ---- views of device-resident data -----------------------------------------
-// Models: structure-of-arrays, band-major, padded to Mp = ceil64(M) so that a
+// Models: structure-of-arrays, band-major, padded to Mp = ceil256(M) so that a
 // wave's 64 lanes read 512 contiguous bytes per band (coalesced).
 struct ModelView {
     const double* y;       // [BT][Mp]  model flux
@@ -27,11 +29,10 @@ struct ModelView {
     int64_t M, Mp;
 };
 // Objects: row-major (N,BT), cleaned (pdf.py:309-311) and pre-derived once per
-// chunk; read wave-uniformly (scalar loads).
+// chunk; read wave-uniformly (scalar loads -> SGPR operands).
 struct ObjView {
     const double* x;       // flux
-    const double* v;       // mode 0: xe^2 ; modes 1,2: 1/xe^2
-    const double* xw;      // mode 2: x/xe^2
+    const double* v;       // mode 0 / C: xe^2 ; modes 1,2: 1/xe^2
     const uint32_t* bits;  // data_mask bits
     const double* slv;     // sum over the B real bands of log(xe^2) (UNMASKED, pdf.py:96-98)
 };
@@ -46,18 +47,30 @@ struct PairOut { double lnl, chi2, scale, shape; int ndim; };
 
 // xlogy(a-1, chi2) - chi2/2 - gammaln(a) - a ln2      (pdf.py:92-93, 228-229)
 __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg) {
-    double xl = (am1 == 0.0 && chi2 == chi2) ? 0.0 : am1 * log(chi2);
+    double xl = am1 * log_pos(chi2);
+    if (am1 == 0.0) xl = (chi2 == chi2) ? 0.0 : chi2;      // xlogy(0, y) = 0 unless y is nan
     return xl - 0.5 * chi2 - lg;
 }
 
-template <int BT, int MODE, bool MASKED>
+// VAR selects the arithmetic variant of one (BT, MODE) kernel:
+//   0  no masked band anywhere, variances in [1e-50,1e50]: mask-free code, ONE
+//      reciprocal per pair (the B per-band quotients are summed over a common
+//      denominator), Newton-refined v_rcp_f64
+//   1  masks present (or B padded up to BT), tame variances: per-band masked terms
+//      with Newton-refined reciprocals
+//   2  anything else (zero/huge/non-finite variances): IEEE division throughout
+enum { VAR_FAST = 0, VAR_MASKED = 1, VAR_SAFE = 2 };
+
+template <int BT, int MODE, int VAR>
 struct Phot {
+    static constexpr bool MASKED = (VAR != VAR_FAST);
+    static constexpr bool SAFE = (VAR == VAR_SAFE);
     ModelView mv;
     ObjView ov;
     LikeParams lp;
 
     struct MR { double y[BT]; double ye2[BT]; uint32_t bits; };
-    struct OR { double x[BT]; double v[BT]; double xw[BT]; uint32_t bits; double slv; };
+    struct OR { double x[BT]; double v[BT]; uint32_t bits; double slv; };
 
     __device__ __forceinline__ void load_model(int64_t j, MR& m) const {
 #pragma unroll
@@ -73,10 +86,14 @@ struct Phot {
         for (int b = 0; b < BT; ++b) {
             o.x[b] = ov.x[i * BT + b];
             o.v[b] = ov.v[i * BT + b];
-            if (MODE == 2) o.xw[b] = ov.xw[i * BT + b];
         }
         o.bits = MASKED ? ov.bits[i] : 0xffffffffu;
         o.slv = ov.slv[i];
+    }
+
+    // num/den: one Newton step on v_rcp_f64 (2e-15 relative, tests/test_hip_fastmath.py)
+    static __device__ __forceinline__ double quot(double num, double den) {
+        return SAFE ? num / den : num * rcp_nr<1>(den);
     }
 
     __device__ __forceinline__ PairOut eval(const OR& o, const MR& m) const {
@@ -93,50 +110,74 @@ struct Phot {
         if (MODE == 0) {
             // tot_var = xe^2 + ye^2 ; chi2 = sum_b m (x-y)^2 / tot_var
             double vprod = 1.0; int vexp = 0;
+            if (!MASKED) {
+                // sum_b t_b/v_b = n/d with (n,d) <- (n v_b + t_b d, d v_b): one reciprocal
+                double num = 0.0, den = 1.0;
 #pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                double v = o.v[b] + m.ye2[b];
-                double d = o.x[b] - m.y[b];
-                double q = (d * d) / v;
-                chi2 = MASKED ? fma(q, tm[b], chi2) : chi2 + q;
-                if (b < lp.nband && !lp.dim_prior) {   // uniform branch
-                    int e; vprod *= frexp(v, &e); vexp += e;
+                for (int b = 0; b < BT; ++b) {
+                    const double v = o.v[b] + m.ye2[b];
+                    const double d = o.x[b] - m.y[b];
+                    const double t = d * d;
+                    if (b == 0) { num = t; den = v; }
+                    else { num = fma(num, v, t * den); den = den * v; }
+                }
+                chi2 = num * rcp_nr<1>(den);
+                if (!lp.dim_prior) {           // uniform branch; log of the product = sum of logs
+                    int e; vprod = frexp(den, &e); vexp = e;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < BT; ++b) {
+                    const double v = o.v[b] + m.ye2[b];
+                    const double d = o.x[b] - m.y[b];
+                    chi2 = fma(quot(d * d, v), tm[b], chi2);
+                    if (b < lp.nband && !lp.dim_prior) {   // uniform branch
+                        int e; vprod *= frexp(v, &e); vexp += e;
+                    }
                 }
             }
-            if (!lp.dim_prior) slogv = log(vprod) + (double)vexp * FZ_LN2;
+            if (!lp.dim_prior) slogv = log_pos(vprod) + (double)vexp * FZ_LN2;
         } else if (MODE == 1) {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
-                double d = o.x[b] - m.y[b];
-                double q = (d * d) * o.v[b];
+                const double d = o.x[b] - m.y[b];
+                const double q = (d * d) * o.v[b];
                 chi2 = MASKED ? fma(q, tm[b], chi2) : chi2 + q;
             }
             slogv = o.slv;
         } else {
-            // inter = sum m y x / var ; shape = sum m y^2 / var ; s = inter/shape
+            // inter = sum m (y x)/var ; shape = sum m (y y)/var ; s = inter/shape.
+            // Both use the SAME 1/var factor, so a model identical to the data gives
+            // inter == shape bit for bit and s == 1 exactly, as in the reference.
             double inter = 0.0, shape = 0.0;
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
-                double yi = m.y[b] * o.xw[b];
-                double ys = (m.y[b] * m.y[b]) * o.v[b];
-                inter = MASKED ? fma(yi, tm[b], inter) : inter + yi;
-                shape = MASKED ? fma(ys, tm[b], shape) : shape + ys;
+                const double w = MASKED ? o.v[b] * tm[b] : o.v[b];
+                inter = fma(m.y[b] * o.x[b], w, inter);
+                shape = fma(m.y[b] * m.y[b], w, shape);
             }
-            double s = inter / shape;
+            double s;
+            if (SAFE || !(shape > 1e-280 && shape < 1e280)) {
+                s = inter / shape;                 // shape == 0 (no usable band) -> nan/inf like NumPy
+            } else {
+                const double rc = rcp_nr<1>(shape);
+                s = inter * rc;
+                s = fma(fma(-s, shape, inter), rc, s);    // residual correction: n/n == 1 exactly
+            }
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
-                double d = fma(-s, m.y[b], o.x[b]);
-                double q = (d * d) * o.v[b];
+                const double d = fma(-s, m.y[b], o.x[b]);
+                const double q = (d * d) * o.v[b];
                 chi2 = MASKED ? fma(q, tm[b], chi2) : chi2 + q;
             }
             r.scale = s; r.shape = shape;
             slogv = o.slv;
         }
         r.chi2 = chi2;
-        double nd = (double)r.ndim;
+        const double nd = (double)r.ndim;
         if (lp.dim_prior) {
-            double a = (MODE == 2) ? 0.5 * (nd - 1.0) : 0.5 * nd;
-            double lg = MASKED ? lp.lgtab[r.ndim] : lp.lg_full;
+            const double a = (MODE == 2) ? 0.5 * (nd - 1.0) : 0.5 * nd;
+            const double lg = MASKED ? lp.lgtab[r.ndim] : lp.lg_full;
             r.lnl = chi2_logpdf(a - 1.0, chi2, lg);
         } else {
             r.lnl = -0.5 * chi2 - 0.5 * (nd * FZ_LN2PI + slogv);
@@ -145,31 +186,38 @@ struct Phot {
     }
 };
 
-// ---- wave64 reductions (DPP/permute via __shfl_xor) ---------------------------
+// ---- wave64 reductions --------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 // online (max, sum-exp) state; NaNs never become the max (Python's builtin max
-// skips them unless first, bruteforce.py:359/619) but do poison the sum
-// (logsumexp -> nan).
+// skips them unless first, bruteforce.py:359/619).  They DO poison logsumexp in the
+// reference; the kernels flag them separately and force levid = nan at the end.
 struct MS { double m, s; };
 __device__ __forceinline__ void ms_init(MS& a) { a.m = -INFINITY; a.s = 0.0; }
+// branch-free: d = l - m is nan when l is nan or both are the same infinity, and
+// then e = 0 and nothing changes; l = -inf gives e = 0 as well.
 __device__ __forceinline__ void ms_push(MS& a, double l) {
-    if (l == -INFINITY) return;                 // exp(-inf - m) = 0 contributes nothing
-    double d = l - a.m;                         // nan if l is nan (or both +inf)
-    double e = exp(-fabs(d));
-    if (d > 0.0) { a.s = fma(a.s, e, 1.0); a.m = l; }
-    else a.s += e;                              // d<=0 or nan
+    const double d = l - a.m;
+    const double e = exp_neg(-fabs(d));         // nan d -> 0: nans are flagged by the caller
+    const bool up = d > 0.0;
+    a.s = fma(a.s, up ? e : 1.0, up ? 1.0 : e); // up: s*e + 1 ; else: s + e
+    a.m = up ? l : a.m;
 }
 __device__ __forceinline__ MS ms_merge(const MS& a, const MS& b) {
     MS r;
     if (b.m == -INFINITY && b.s == 0.0) return a;
     if (a.m == -INFINITY && a.s == 0.0) return b;
     r.m = fmax(a.m, b.m);
-    r.s = a.s * exp(a.m - r.m) + b.s * exp(b.m - r.m);
+    r.s = a.s * exp_neg(a.m - r.m) + b.s * exp_neg(b.m - r.m);
     return r;
 }
 __device__ __forceinline__ MS wave_ms(MS a) {

@@ -1,0 +1,68 @@
+// fp64 transcendental/division helpers sized for this path (gfx950).
+//
+// The likelihood path needs log(chi2), exp(lnl - max) and 1/var per object-model
+// pair.  The OCML versions are correctly rounded-ish and cost ~100 / ~50 / ~11
+// fp64 instructions; these cost ~15 / ~17 / ~3 and keep ~1e-15 relative accuracy
+// (absolute for log), seven orders of magnitude inside the 1e-5 parity bar.
+// Accuracy is pinned by tests/test_hip_fastmath.py against NumPy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fz_tables.h"
+
+namespace fz {
+
+// 1/v: hardware v_rcp_f64 seed + NITER Newton steps (each 2 FMAs).
+template <int NITER>
+__device__ __forceinline__ double rcp_nr(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+#pragma unroll
+    for (int k = 0; k < NITER; ++k) {
+        const double e = fma(-v, r, 1.0);
+        r = fma(r, e, r);
+    }
+    return r;
+}
+
+// natural log for finite x > 0 (denormals included); x == 0 -> -inf, x == +inf -> +inf,
+// NaN or x < 0 -> NaN.  |abs error| < 4e-16 + 2e-16*|log x|.
+__device__ __forceinline__ double log_pos(double x) {
+    const double mant = __builtin_amdgcn_frexp_mant(x);          // [0.5,1)
+    const int ex = __builtin_amdgcn_frexp_exp(x);
+    const unsigned hi = (unsigned)__double2hiint(mant);
+    const unsigned idx = (hi >> 13) & 127u;                      // top 7 fraction bits
+    const double2 t = reinterpret_cast<const double2*>(FZ_LOG_TAB)[idx];
+    const double r = fma(mant, t.x, -1.0);                       // |r| <= 2^-8
+    // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
+    double p = fma(r, -1.0 / 6.0, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r * r, p, r);
+    double l = fma((double)ex, 0.6931471805599453, t.y) + p;
+    // +normal | +denormal is the only class the table path is valid for; anything
+    // else is rare, so the fix-up sits behind a wave-uniform branch.
+    const bool ok = __builtin_amdgcn_class(x, 0x180);
+    if (!__all(ok)) {
+        if (!ok) l = (x == 0.0) ? -INFINITY : ((x == INFINITY) ? INFINITY : NAN);
+    }
+    return l;
+}
+
+// exp(x) for x <= 0 (what the softmax needs); x <= -745.2 -> 0.  NaN input is NOT
+// propagated (callers track NaNs separately).  Relative error < 3e-16.
+__device__ __forceinline__ double exp_neg(double x) {
+    x = fmax(x, -800.0);                                         // also maps NaN -> -800
+    const double k = rint(x * 92.33248261689366);                // 64/ln2
+    double r = fma(k, -0.010830424696249145, x);                 // ln2/64 hi
+    r = fma(k, -3.623510646634843e-19, r);                       // ln2/64 lo  (hi+lo good to 1e-35)
+    const int ki = (int)k;
+    const double t = FZ_EXP_TAB[ki & 63];
+    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(t * p, ki >> 6);
+}
+
+}  // namespace fz

@@ -1,0 +1,111 @@
+// Per-band-count instantiations of the photometric kernels.  Compiled once per
+// FZ_BT in {5, 8, 16} (separate translation units so they build in parallel).
+#ifndef FZ_BT
+#error "compile with -DFZ_BT=5|8|16"
+#endif
+#include "fz_ctx.h"
+#include "fz_kernels.h"
+#include "fz_launch.h"
+#include "fz_modec.h"
+
+using namespace fz;
+
+#define FZ_CAT_(a, b) a##b
+#define FZ_CAT(a, b) FZ_CAT_(a, b)
+#define FZ_NAME(base) FZ_CAT(base, FZ_BT)
+
+// VAR_FAST exists only when BT equals the real band count (B == 5): padded band
+// counts always carry mask bits.
+#if FZ_BT == 5
+#define FZ_SWITCH_VAR(MODE_, CALL)                                         \
+    switch (var) {                                                         \
+        case 0: { CALL(FZ_BT, MODE_, 0); } break;                          \
+        case 1: { CALL(FZ_BT, MODE_, 1); } break;                          \
+        default: { CALL(FZ_BT, MODE_, 2); } break;                         \
+    }
+#else
+#define FZ_SWITCH_VAR(MODE_, CALL)                                         \
+    switch (var) {                                                         \
+        case 2: { CALL(FZ_BT, MODE_, 2); } break;                          \
+        default: { CALL(FZ_BT, MODE_, 1); } break;                         \
+    }
+#endif
+#define FZ_SWITCH(CALL)                                                    \
+    switch (mode) {                                                        \
+        case 0: FZ_SWITCH_VAR(0, CALL) break;                              \
+        case 1: FZ_SWITCH_VAR(1, CALL) break;                              \
+        case 2: FZ_SWITCH_VAR(2, CALL) break;                              \
+        default: return fail(-1, "internal: bad likelihood mode %d", mode); \
+    }
+
+int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, double* lnl, double* chi2,
+                          int64_t* ndim, double* scale, double* serr) {
+    constexpr int TO = 16;
+    const int64_t M = c->M;
+    dim3 grid((unsigned)((n + TO - 1) / TO), (unsigned)((M + 255) / 256));
+    Timer t(c, &c->tm.ms_planes, &c->tm.n_planes);
+#define FZ_CALL_PLANES(BT_, MODE_, VAR_)                                                                  \
+    PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
+    hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, chi2, \
+                       ndim, scale, serr);
+    FZ_SWITCH(FZ_CALL_PLANES)
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const fz_kde_opts* ko, double* lmap,
+                              double* levid, double* pdfs) {
+    const int64_t M = c->M;
+#define FZ_CALL_FUSED(BT_, MODE_, VAR_)                                                                   \
+    PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
+    return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
+    FZ_SWITCH(FZ_CALL_FUSED)
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mode C driver on a prepared chunk: leaves converged state in c->d_mc[*]
+// ---------------------------------------------------------------------------
+template <int BT, bool MASKED>
+static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o) {
+    const int64_t M = c->M;
+    const size_t pl = (size_t)n * M * 8;
+    for (int k = 0; k < 4; ++k) FZCHK(c->d_mc[k].ensure(pl));
+    FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(n * 4)); FZCHK(c->d_mccnt.ensure(64));
+    ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
+    st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.firstnan = c->d_mcfn.as<int>();
+    st.active = c->d_mcact.as<int>(); st.nactive = c->d_mccnt.as<int>();
+    HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
+    HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
+    HIPCHK(hipMemsetAsync(st.active, 0xff, n * 4, c->stream));       // all active (non-zero)
+    ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B;
+    const int64_t tiles = (M + 255) / 256;
+    const int64_t nblk = n * tiles;
+    if (nblk > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
+    const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
+    Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
+    hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 1);
+    int it = 0, nact = 1;
+    while (nact > 0) {
+        if (it >= max_iter)
+            return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
+                            "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
+        HIPCHK(hipMemsetAsync(st.nactive, 0, 4, c->stream));
+        hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 0);
+        hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, st, n, o->ltol);
+        HIPCHK(hipMemcpyAsync(&nact, st.nactive, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ++it;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o) {
+#if FZ_BT == 5
+    return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o) : run_modec<FZ_BT, true>(c, n, o);
+#else
+    (void)var;
+    return run_modec<FZ_BT, true>(c, n, o);
+#endif
+}

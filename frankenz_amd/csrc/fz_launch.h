@@ -1,0 +1,110 @@
+// Launch geometry of the softmax / KDE kernels (templates over the ln-weight source).
+#pragma once
+#include "fz_ctx.h"
+#include "fz_kernels.h"
+
+inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
+    using namespace fz;
+    if (c->label_mode == 0) return fail(-1, "labels have not been uploaded");
+    if (c->label_M != c->M)
+        return fail(-1, "labels (%lld) do not match the model count (%lld)", (long long)c->label_M, (long long)c->M);
+    memset(&kv, 0, sizeof kv);
+    kv.G = c->G;
+    kv.norm = c->d_norm.as<double>();
+    if (c->label_mode == 1) {
+        kv.pos = c->d_pos.as<int32_t>(); kv.cls = c->d_cls.as<int32_t>();
+        kv.widths = c->d_widths.as<int64_t>(); kv.offsets = c->d_offsets.as<int64_t>(); kv.kern = c->d_kern.as<double>();
+        kv.w0 = c->w0; kv.koff0 = c->h_offsets[c->cls0];
+        kv.kmode = c->single_cls ? KDE_HIST : KDE_DICT;
+        kv.acc_stride = (int)(kv.kmode == KDE_HIST ? c->G + 2 * c->w0 : c->G);
+    } else {
+        kv.ly = c->d_ly.as<double>(); kv.lstd = c->d_lstd.as<double>(); kv.lo = c->d_lo.as<int32_t>(); kv.hi = c->d_hi.as<int32_t>();
+        kv.grid = c->d_grid.as<double>();
+        kv.kmode = KDE_GRID; kv.acc_stride = (int)c->G;
+    }
+    if ((size_t)kv.acc_stride * 8 > 160 * 1024)
+        return fail(-5, "PDF grid of %lld points needs %zu B of LDS per object (> 160 KiB)", (long long)kv.G,
+                    (size_t)kv.acc_stride * 8);
+    return 0;
+}
+
+template <class SRC>
+int fz_launch_stats(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, double* lmap, double* levid) {
+    constexpr int TW = 4, WPB = 4;
+    const int64_t per = TW * WPB;
+    Timer t(c, &c->tm.ms_stats, &c->tm.n_stats);
+    hipLaunchKernelGGL((fz::k_stats<SRC, TW>), dim3((unsigned)((n + per - 1) / per)), dim3(WPB * 64), 0, c->stream, src, n, M,
+                       linear, lmap, levid);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <class SRC, int TW>
+int fz_launch_kde_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int wpb, int64_t n, int64_t M, int linear,
+                     const double* lmap, const double* levid, const fz_kde_opts* ko, double* pdfs) {
+    const int64_t per = (int64_t)TW * wpb;
+    const size_t lds = (size_t)wpb * TW * kv.acc_stride * 8;
+    auto kern = fz::k_kde<SRC, TW>;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Timer t(c, &c->tm.ms_kde, &c->tm.n_kde);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + per - 1) / per)), dim3(wpb * 64), lds, c->stream, src, kv, n, M, linear,
+                       lmap, levid, ko->wt_thresh, ko->normalize, pdfs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <class SRC>
+int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, const double* lmap, const double* levid,
+                  const fz_kde_opts* ko, double* pdfs) {
+    fz::KdeView kv;
+    FZCHK(fz_kde_view(c, kv));
+    // objects per wave / waves per block from the LDS each object's accumulator needs
+    const size_t per_obj = (size_t)kv.acc_stride * 8, budget = 160 * 1024;
+    if (per_obj * 8 <= 53 * 1024) return fz_launch_kde_tw<SRC, 2>(c, src, kv, 4, n, M, linear, lmap, levid, ko, pdfs);
+    if (per_obj * 4 <= budget) return fz_launch_kde_tw<SRC, 1>(c, src, kv, 4, n, M, linear, lmap, levid, ko, pdfs);
+    if (per_obj * 2 <= budget) return fz_launch_kde_tw<SRC, 1>(c, src, kv, 2, n, M, linear, lmap, levid, ko, pdfs);
+    return fz_launch_kde_tw<SRC, 1>(c, src, kv, 1, n, M, linear, lmap, levid, ko, pdfs);
+}
+
+// single-pass kernel; returns +1 (not an error) when its candidate workspace does
+// not fit the budget and the caller should take the two-pass route
+template <class SRC, int TW>
+int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                       double* lmap, double* levid, double* pdfs) {
+    const size_t per_obj = (size_t)kv.acc_stride * 8;
+    int wpb = 4;
+    while (wpb > 1 && per_obj * wpb > 64 * 1024) wpb >>= 1;
+    if (per_obj * wpb > 160 * 1024) return 1;
+    const int64_t groups = (n + TW - 1) / TW;
+    const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
+    int64_t waves = std::min<int64_t>(groups, (int64_t)c->cu_count * 8);
+    const int64_t fit = (int64_t)(c->ws_limit / per_wave);
+    if (fit < std::min<int64_t>(groups, (int64_t)c->cu_count * 2)) return 1;     // too few waves to fill the chip
+    waves = std::min(waves, fit);
+    const int64_t blocks = (waves + wpb - 1) / wpb;
+    FZCHK(c->d_cand.ensure((size_t)blocks * wpb * per_wave));
+    const size_t lds = (size_t)wpb * per_obj;
+    auto kern = fz::k_fused<SRC, TW>;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(wpb * 64), lds, c->stream, src, kv, n, M, ko->wt_thresh,
+                       ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// fit_predict on a prepared chunk: single pass when possible, else two passes
+template <class SRC>
+int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap,
+                         double* levid, double* pdfs) {
+    fz::KdeView kv;
+    FZCHK(fz_kde_view(c, kv));
+    if (!c->force_twopass) {
+        // few objects: one per wave so that the chunk spreads over the chip
+        const int r = (n >= (int64_t)c->cu_count * 16) ? fz_launch_fused_tw<SRC, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs)
+                                                       : fz_launch_fused_tw<SRC, 1>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        if (r <= 0) return r;
+    }
+    FZCHK(fz_launch_stats(c, src, n, M, 0, lmap, levid));
+    return fz_launch_kde(c, src, n, M, 0, lmap, levid, ko, pdfs);
+}

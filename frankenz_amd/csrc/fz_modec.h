@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_
     }
 }
 
-__global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
+static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nc) return;
     if (!st.active[i]) return;
@@ -110,7 +110,7 @@ __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
 }
 
 // after convergence: dim prior (pdf.py:226-229) and the output planes
-__global__ __launch_bounds__(256) void k_modec_final(ModeCState st, ModelView mv, const uint32_t* obits,
+static __global__ __launch_bounds__(256) void k_modec_final(ModeCState st, ModelView mv, const uint32_t* obits,
                                                      int masked, int nband, int dim_prior,
                                                      const double* lgtab, int64_t Nc, int64_t M,
                                                      double* lnl, double* chi2, int64_t* ndim,

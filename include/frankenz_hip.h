@@ -54,6 +54,7 @@ typedef struct fz_kde_opts {
  * the context's own stream). */
 typedef struct fz_timing {
     double  ms_planes;  int64_t n_planes;   /* materialising fit kernel       */
+    double  ms_fused;   int64_t n_fused;    /* single-pass fit_predict kernel */
     double  ms_stats;   int64_t n_stats;    /* pass 1: max + logsumexp        */
     double  ms_kde;     int64_t n_kde;      /* pass 2: threshold + KDE stack  */
     double  ms_modec;   int64_t n_modec;    /* mode-C fixed-point iterations  */
@@ -131,6 +132,11 @@ int  fz_knn_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t 
                         const fz_kde_opts* kde, int64_t* neighbors, int64_t* nnbr,
                         double* lnlike, double* chi2, int64_t* ndim, double* scale,
                         double* scale_err, double* pdfs, double* lmap, double* levid);
+
+/* diagnostic: evaluate one of the library's device math helpers elementwise
+ * (which: 0 v_rcp_f64 seed, 1 / 2 rcp with one / two Newton steps, 3 log_pos,
+ * 4 exp_neg).  Used by tests to pin their accuracy against NumPy. */
+int  fz_selftest_math(fz_ctx* ctx, int32_t which, const double* x, int64_t n, double* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,51 @@
+"""Accuracy of the device math helpers (fz_fastmath.h) against NumPy, on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run(which, x):
+    from frankenz_amd.engine import get_engine
+    from frankenz_amd._lib import check, ptr
+    eng = get_engine()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    check(eng.lib.fz_selftest_math(eng.h, which, ptr(x), len(x), ptr(out)))
+    return out
+
+
+def test_rcp_newton():
+    rs = np.random.RandomState(0)
+    x = np.exp(rs.uniform(-200, 200, 200000)) * rs.choice([-1, 1], 200000)
+    seed = np.abs(run(0, x) * x - 1).max()
+    e1 = np.abs(run(1, x) * x - 1).max()
+    e2 = np.abs(run(2, x) * x - 1).max()
+    print("rcp rel err: seed %.3g, 1 step %.3g, 2 steps %.3g" % (seed, e1, e2))
+    assert e1 < 1e-12 and e2 < 5e-16
+
+
+def test_log_pos():
+    rs = np.random.RandomState(1)
+    x = np.concatenate([np.exp(rs.uniform(-700, 700, 200000)), rs.uniform(0.5, 2.0, 100000),
+                        1 + rs.uniform(-1e-6, 1e-6, 1000), [5e-324, 1e-310, 2.2250738585072014e-308, 1.0]])
+    got, want = run(3, x), np.log(x)
+    err = np.abs(got - want) / (1 + np.abs(want))
+    print("log_pos max scaled err %.3g" % err.max())
+    assert err.max() < 1e-15
+    sp = run(3, np.array([0.0, np.inf, np.nan, -1.0]))
+    assert sp[0] == -np.inf and sp[1] == np.inf and np.isnan(sp[2]) and np.isnan(sp[3])
+
+
+def test_exp_neg():
+    rs = np.random.RandomState(2)
+    x = -np.concatenate([rs.uniform(0, 745, 200000), rs.uniform(0, 2, 100000), [0.0, 1e-300, 744.9, 800., 1e9]])
+    got, want = run(4, x), np.exp(x)
+    ok = want > 1e-300
+    rel = np.abs(got[ok] / want[ok] - 1)
+    print("exp_neg max rel err %.3g" % rel.max())
+    assert rel.max() < 1e-15
+    assert np.all(got[~ok] <= 1e-300) and got[-1] == 0.0
+    assert run(4, np.array([-np.inf]))[0] == 0.0
