@@ -51,7 +51,7 @@ struct fz_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     fz_timing tm{};
-    int64_t ws_limit = (int64_t)16 << 30;
+    int64_t ws_limit = (int64_t)32 << 30;
     int cu_count = 256;
     int force_twopass = 0;     // diagnostics: disable the single-pass fused kernel
 
@@ -73,7 +73,7 @@ struct fz_ctx {
     DevBuf d_lmap, d_levid, d_pdfs;
     DevBuf d_pl[5];            // staging planes
     DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt;
-    DevBuf d_cand;             // candidate lists of the single-pass fused kernel
+    DevBuf d_cand, d_kv;       // candidate lists / KDE table view of the single-pass fused kernel
     // knn
     int knn_K = 0, knn_F = 0; int64_t knn_M = 0;
     DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm;
@@ -82,7 +82,7 @@ struct fz_ctx {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
                                   &d_cls, &d_norm, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_mcerr,
-                                  &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
+                                  &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_kv, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
         for (auto& b : d_pl) v.push_back(&b);
         for (auto& b : d_mc) v.push_back(&b);
         return v;

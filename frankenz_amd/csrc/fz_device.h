@@ -46,8 +46,8 @@ struct LikeParams {
 struct PairOut { double lnl, chi2, scale, shape; int ndim; };
 
 // xlogy(a-1, chi2) - chi2/2 - gammaln(a) - a ln2      (pdf.py:92-93, 228-229)
-__device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg) {
-    double xl = am1 * log_pos(chi2);
+__device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg, const FastTabs& tb) {
+    double xl = am1 * log_pos(chi2, tb);
     if (am1 == 0.0) xl = (chi2 == chi2) ? 0.0 : chi2;      // xlogy(0, y) = 0 unless y is nan
     return xl - 0.5 * chi2 - lg;
 }
@@ -68,6 +68,7 @@ struct Phot {
     ModelView mv;
     ObjView ov;
     LikeParams lp;
+    FastTabs tb;           // set by the kernel (LDS or global copy of the log/exp tables)
 
     struct MR { double y[BT]; double ye2[BT]; uint32_t bits; };
     struct OR { double x[BT]; double v[BT]; uint32_t bits; double slv; };
@@ -89,6 +90,20 @@ struct Phot {
         }
         o.bits = MASKED ? ov.bits[i] : 0xffffffffu;
         o.slv = ov.slv[i];
+    }
+    // Object rows parked in LDS by the owning wave ((2 BT + 2) doubles each) and read
+    // back with broadcast ds_reads inside the model loop: keeps TW objects' rows out
+    // of the register file for the whole loop.
+    static constexpr int OBJ_DOUBLES = 2 * BT + 2;
+    __device__ __forceinline__ void park_obj(int64_t i, double* dst, int lane) const {
+        if (lane < BT) { dst[lane] = ov.x[i * BT + lane]; dst[BT + lane] = ov.v[i * BT + lane]; }
+        if (lane == BT) { dst[2 * BT] = ov.slv[i]; dst[2 * BT + 1] = __hiloint2double(0, MASKED ? (int)ov.bits[i] : -1); }
+    }
+    __device__ __forceinline__ void load_obj_lds(const double* p, OR& o) const {
+#pragma unroll
+        for (int b = 0; b < BT; ++b) { o.x[b] = p[b]; o.v[b] = p[BT + b]; }
+        o.slv = p[2 * BT];
+        o.bits = MASKED ? (uint32_t)__double2loint(p[2 * BT + 1]) : 0xffffffffu;
     }
 
     // num/den: one Newton step on v_rcp_f64 (2e-15 relative, tests/test_hip_fastmath.py)
@@ -136,7 +151,7 @@ struct Phot {
                     }
                 }
             }
-            if (!lp.dim_prior) slogv = log_pos(vprod) + (double)vexp * FZ_LN2;
+            if (!lp.dim_prior) slogv = log_pos(vprod, tb) + (double)vexp * FZ_LN2;
         } else if (MODE == 1) {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
@@ -178,7 +193,7 @@ struct Phot {
         if (lp.dim_prior) {
             const double a = (MODE == 2) ? 0.5 * (nd - 1.0) : 0.5 * nd;
             const double lg = MASKED ? lp.lgtab[r.ndim] : lp.lg_full;
-            r.lnl = chi2_logpdf(a - 1.0, chi2, lg);
+            r.lnl = chi2_logpdf(a - 1.0, chi2, lg, tb);
         } else {
             r.lnl = -0.5 * chi2 - 0.5 * (nd * FZ_LN2PI + slogv);
         }
@@ -205,9 +220,9 @@ struct MS { double m, s; };
 __device__ __forceinline__ void ms_init(MS& a) { a.m = -INFINITY; a.s = 0.0; }
 // branch-free: d = l - m is nan when l is nan or both are the same infinity, and
 // then e = 0 and nothing changes; l = -inf gives e = 0 as well.
-__device__ __forceinline__ void ms_push(MS& a, double l) {
+__device__ __forceinline__ void ms_push(MS& a, double l, const FastTabs& tb) {
     const double d = l - a.m;
-    const double e = exp_neg(-fabs(d));         // nan d -> 0: nans are flagged by the caller
+    const double e = exp_neg(-fabs(d), tb);     // nan d -> 0: nans are flagged by the caller
     const bool up = d > 0.0;
     a.s = fma(a.s, up ? e : 1.0, up ? 1.0 : e); // up: s*e + 1 ; else: s + e
     a.m = up ? l : a.m;

@@ -23,14 +23,32 @@ __device__ __forceinline__ double rcp_nr(double v) {
     return r;
 }
 
+// Reduction tables.  The global copies (fz_tables.h) serve one-off uses; kernels that
+// call log/exp per pair keep a copy in LDS (FastTabs) so that a lookup is one
+// ds_read instead of a global load sitting in the vector-memory queue.
+struct FastTabs {
+    const double2* logt;     // [128] {1/c, log c}
+    const double* expt;      // [64]  2^(j/64)
+};
+#define FZ_TABS_DOUBLES (256 + 64)
+__device__ __forceinline__ FastTabs global_tabs() {
+    FastTabs t; t.logt = reinterpret_cast<const double2*>(FZ_LOG_TAB); t.expt = FZ_EXP_TAB; return t;
+}
+// copy the tables into LDS at `dst` (FZ_TABS_DOUBLES doubles); caller synchronises
+__device__ __forceinline__ FastTabs stage_tabs(double* dst, int tid, int nthreads) {
+    for (int k = tid; k < 256; k += nthreads) dst[k] = FZ_LOG_TAB[k];
+    for (int k = tid; k < 64; k += nthreads) dst[256 + k] = FZ_EXP_TAB[k];
+    FastTabs t; t.logt = reinterpret_cast<const double2*>(dst); t.expt = dst + 256; return t;
+}
+
 // natural log for finite x > 0 (denormals included); x == 0 -> -inf, x == +inf -> +inf,
 // NaN or x < 0 -> NaN.  |abs error| < 4e-16 + 2e-16*|log x|.
-__device__ __forceinline__ double log_pos(double x) {
+__device__ __forceinline__ double log_pos(double x, const FastTabs& tb) {
     const double mant = __builtin_amdgcn_frexp_mant(x);          // [0.5,1)
     const int ex = __builtin_amdgcn_frexp_exp(x);
     const unsigned hi = (unsigned)__double2hiint(mant);
     const unsigned idx = (hi >> 13) & 127u;                      // top 7 fraction bits
-    const double2 t = reinterpret_cast<const double2*>(FZ_LOG_TAB)[idx];
+    const double2 t = tb.logt[idx];
     const double r = fma(mant, t.x, -1.0);                       // |r| <= 2^-8
     // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
     double p = fma(r, -1.0 / 6.0, 0.2);
@@ -40,23 +58,26 @@ __device__ __forceinline__ double log_pos(double x) {
     p = fma(r * r, p, r);
     double l = fma((double)ex, 0.6931471805599453, t.y) + p;
     // +normal | +denormal is the only class the table path is valid for; anything
-    // else is rare, so the fix-up sits behind a wave-uniform branch.
+    // else is rare, so the fix-up sits behind a real wave-uniform branch (the empty
+    // asm keeps the compiler from turning it back into selects).
     const bool ok = __builtin_amdgcn_class(x, 0x180);
-    if (!__all(ok)) {
+    if (__ballot(!ok) != 0ull) {
+        asm volatile("" ::: "memory");
         if (!ok) l = (x == 0.0) ? -INFINITY : ((x == INFINITY) ? INFINITY : NAN);
     }
     return l;
 }
+__device__ __forceinline__ double log_pos(double x) { return log_pos(x, global_tabs()); }
 
 // exp(x) for x <= 0 (what the softmax needs); x <= -745.2 -> 0.  NaN input is NOT
 // propagated (callers track NaNs separately).  Relative error < 3e-16.
-__device__ __forceinline__ double exp_neg(double x) {
+__device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
     x = fmax(x, -800.0);                                         // also maps NaN -> -800
     const double k = rint(x * 92.33248261689366);                // 64/ln2
     double r = fma(k, -0.010830424696249145, x);                 // ln2/64 hi
     r = fma(k, -3.623510646634843e-19, r);                       // ln2/64 lo  (hi+lo good to 1e-35)
     const int ki = (int)k;
-    const double t = FZ_EXP_TAB[ki & 63];
+    const double t = tb.expt[ki & 63];
     double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
     p = fma(r, p, 1.0 / 6.0);
     p = fma(r, p, 0.5);
@@ -64,5 +85,6 @@ __device__ __forceinline__ double exp_neg(double x) {
     p = fma(r, p, 1.0);
     return ldexp(t * p, ki >> 6);
 }
+__device__ __forceinline__ double exp_neg(double x) { return exp_neg(x, global_tabs()); }
 
 }  // namespace fz

@@ -24,10 +24,12 @@ namespace fz {
 // ---- a source that reads ln-weights from a materialised (N,M) plane ----------
 struct PlaneSrc {
     const double* p; int64_t ld;
+    FastTabs tb;
     struct MR {};
     struct OR { const double* row; };
     __device__ __forceinline__ void load_model(int64_t, MR&) const {}
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const { o.row = p + i * ld; }
+    __device__ __forceinline__ void load_obj_fresh(int64_t i, OR& o) const { o.row = p + i * ld; }
     __device__ __forceinline__ double lnl(const OR& o, const MR&, int64_t j, bool valid) const {
         return valid ? o.row[j] : -INFINITY;
     }
@@ -40,13 +42,41 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
         const double l = P::eval(o, m).lnl;       // pad lanes hold benign data; no divergent branch
         return valid ? l : -INFINITY;
     }
+
+    // ---- LDS-staged model tiles (k_fused) ----
+    // A tile is TILE consecutive models: NARR rows of TILE doubles (y per band, then
+    // ye2 per band in mode A) followed by the TILE mask words.  Every row is a
+    // contiguous, 16-B aligned slice of the SoA arrays, so staging is plain
+    // 16-B-per-lane copies and reading it back is conflict-free ds_read_b64.
+    static constexpr int TILE = 256;
+    static constexpr int NARR = BT + (MODE == 0 ? BT : 0);
+    static constexpr int TILE_DOUBLES = NARR * TILE + (P::MASKED ? TILE / 2 : 0);
+    static constexpr int NCHUNK = TILE_DOUBLES / 2;                 // 16-byte chunks
+    __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
+        const int a = ch / (TILE / 2), off = ch % (TILE / 2);
+        const double* src;
+        if (a < BT) src = P::mv.y + (int64_t)a * P::mv.Mp + tile * TILE;
+        else if (a < NARR) src = P::mv.ye2 + (int64_t)(a - BT) * P::mv.Mp + tile * TILE;
+        else src = reinterpret_cast<const double*>(P::mv.bits + tile * TILE);      // TILE 4-byte words
+        return reinterpret_cast<const double2*>(src)[off];
+    }
+    __device__ __forceinline__ void load_model_lds(const double* t, int k, typename P::MR& m) const {
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            m.y[b] = t[b * TILE + k];
+            if (MODE == 0) m.ye2[b] = t[(BT + b) * TILE + k];
+        }
+        m.bits = P::MASKED ? reinterpret_cast<const uint32_t*>(t + NARR * TILE)[k] : 0xffffffffu;
+    }
 };
 
 // ---- materialising fit ------------------------------------------------------
 template <class PH, int TO>
-__global__ __launch_bounds__(256) void k_planes(PH ph, int64_t N, int64_t M, double* __restrict__ lnl,
+__global__ __launch_bounds__(256) void k_planes(PH ph_, int64_t N, int64_t M, double* __restrict__ lnl,
                                                 double* __restrict__ chi2, int64_t* __restrict__ ndim,
                                                 double* __restrict__ scale, double* __restrict__ serr) {
+    PH ph = ph_;
+    ph.tb = global_tabs();
     const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x;
     const bool valid = j < M;
     typename PH::MR m;
@@ -152,8 +182,10 @@ __device__ __forceinline__ void kde_finalize(const KdeView& kv, const double* ro
 // ---- pass 1: per-object max and logsumexp ------------------------------------
 // linear=1: rows are linear weights; only the max is produced (np.max: NaN wins).
 template <class SRC, int TW>
-__global__ __launch_bounds__(256) void k_stats(SRC src, int64_t N, int64_t M, int linear,
+__global__ __launch_bounds__(256) void k_stats(SRC src_, int64_t N, int64_t M, int linear,
                                                double* __restrict__ lmap, double* __restrict__ levid) {
+    SRC src = src_;
+    src.tb = global_tabs();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * TW;
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(256) void k_stats(SRC src, int64_t N, int64_t M, in
             const double l = src.lnl(ob[o], m, j, valid);
             if (l != l) { anynan |= 1u << o; if (j == 0) firstnan |= 1u << o; }
             if (linear) { if (l > st[o].m) st[o].m = l; }
-            else ms_push(st[o], l);
+            else ms_push(st[o], l, src.tb);
         }
     }
 #pragma unroll
@@ -199,11 +231,13 @@ __global__ __launch_bounds__(256) void k_stats(SRC src, int64_t N, int64_t M, in
 
 // ---- pass 2: threshold + weighted kernel stack ---------------------------------
 template <class SRC, int TW>
-__global__ __launch_bounds__(256) void k_kde(SRC src, KdeView kv, int64_t N, int64_t M, int linear,
+__global__ __launch_bounds__(256) void k_kde(SRC src_, KdeView kv, int64_t N, int64_t M, int linear,
                                              const double* __restrict__ lmap,
                                              const double* __restrict__ levid, double wt_thresh,
                                              int normalize, double* __restrict__ pdfs) {
     extern __shared__ double smem[];
+    SRC src = src_;
+    src.tb = global_tabs();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * TW;
@@ -227,7 +261,7 @@ __global__ __launch_bounds__(256) void k_kde(SRC src, KdeView kv, int64_t N, int
         } else {
             le[o] = levid[i];
             ok[o] = (i0 + o < N) && (le[o] - le[o] == 0.0);   // finite evidence
-            thr[o] = wt_thresh * exp_neg(lm - le[o]);         // wt_thresh * max(wt)
+            thr[o] = wt_thresh * exp_neg(lm - le[o], src.tb); // wt_thresh * max(wt)
             lthr[o] = (wt_thresh > 0.0) ? lm + log(wt_thresh) - 1e-3 : -INFINITY;
         }
     }
@@ -242,7 +276,7 @@ __global__ __launch_bounds__(256) void k_kde(SRC src, KdeView kv, int64_t N, int
             const double l = src.lnl(ob[o], m, j, valid);
             const bool cand = valid && (linear ? true : (l > lthr[o]));
             if (!__any(cand)) continue;                             // wave-uniform
-            const double w = linear ? l : exp_neg(l - le[o]);
+            const double w = linear ? l : exp_neg(l - le[o], src.tb);
             const bool sel = cand && (w > thr[o]);                  // strict, pdf.py:510/591
             kde_scatter(kv, acc + o * kv.acc_stride, sel, w, j, lane);
         }
@@ -258,96 +292,165 @@ __global__ __launch_bounds__(256) void k_kde(SRC src, KdeView kv, int64_t N, int
 // ---- single pass: likelihood + softmax statistics + candidates -> PDF -----------
 struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 store
 
-// Every wave walks its object groups (TW objects each) with a grid stride and owns a
-// private candidate buffer of TW x cap entries (cap = M: it can never overflow).
+// Block = NW waves that stream the model set TOGETHER through double-buffered LDS
+// tiles (each tile is fetched from L2/HBM once per block, not once per wave), while
+// every wave keeps its own TW objects: per-object reductions stay private to a wave.
+// Waves walk their object groups with a grid stride; each owns a candidate buffer of
+// TW x cap entries (cap = M: it can never overflow).
+//
 // A pair is recorded when its lnl is within the weight threshold of the best lnl
 // seen SO FAR (per lane, tightened every 16 steps with the wave-wide best): a
 // superset of the pairs with wt > wt_thresh * max(wt), because the running best only
 // grows.  The exact test (pdf.py:510 / 591, strict >) is applied afterwards with the
-// final max and evidence.
-template <class SRC, int TW>
-__global__ __launch_bounds__(256) void k_fused(SRC src, KdeView kv, int64_t N, int64_t M, double wt_thresh,
-                                               int normalize, Cand* __restrict__ cand, int64_t cap,
-                                               double* __restrict__ lmap, double* __restrict__ levid,
-                                               double* __restrict__ pdfs) {
+// final max and evidence, then the kernels are stacked and the PDF normalised.
+template <class SRC, int TW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
+                                                    int M, double wt_thresh, int normalize,
+                                                    Cand* __restrict__ cand, int64_t cap,
+                                                    double* __restrict__ lmap, double* __restrict__ levid,
+                                                    double* __restrict__ pdfs) {
+    // LDS (doubles): [2][TILE_DOUBLES] model tiles, aliased outside the model loop by
+    // the [NW][acc_stride] PDF rows | [NW][TW][4] per-object results | log/exp tables
+    // | [NW][TW][OBJ_DOUBLES] object rows.
     extern __shared__ double smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    double* row = smem + (size_t)wave * kv.acc_stride;            // one object at a time
+    constexpr int TILE = SRC::TILE, TD = SRC::TILE_DOUBLES, NCH = SRC::NCHUNK, NT = NW * 64;
+    constexpr int CPT = (NCH + NT - 1) / NT;                      // staging chunks per thread
+    constexpr int OD = SRC::OBJ_DOUBLES;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t gw = (int64_t)blockIdx.x * NW + wave;
+    const int64_t ngroups = (N + TW - 1) / TW;
+    const int64_t nrounds = (ngroups + nwaves - 1) / nwaves;      // same for every wave: barriers stay aligned
+    const int ntiles = (M + TILE - 1) / TILE;
+    const int big = (2 * TD > NW * acc_stride) ? 2 * TD : NW * acc_stride;
+    double* row = smem + (size_t)wave * acc_stride;               // valid only outside the model loop
+    double* res = smem + big + wave * (TW * 4);                   // {lmap, levid, max, count} per object
+    double* tabs = smem + big + NW * TW * 4;
+    double* objs = tabs + FZ_TABS_DOUBLES + wave * (TW * OD);
+    SRC src = src_;
+    src.tb = stage_tabs(tabs, tid, NT);
+    const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
 
-    for (int64_t g = gw; g * TW < N; g += nwaves) {
-        const int64_t i0 = g * TW;
-        typename SRC::OR ob[TW];
+    for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
+        const int64_t g = gw + rnd * nwaves;
+        const bool work = g < ngroups;                            // wave-uniform
+        const int64_t i0 = work ? g * TW : 0;
         MS st[TW];
-        double best[TW];                 // wave-wide best lnl (refreshed every 16 steps)
         int cnt[TW];
         unsigned firstnan = 0, anynan = 0;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            src.load_obj(i0 + o < N ? i0 + o : N - 1, ob[o]);
-            ms_init(st[o]);
-            best[o] = -INFINITY;
-            cnt[o] = 0;
+            ms_init(st[o]); cnt[o] = 0;
+            src.park_obj(i0 + o < N ? i0 + o : N - 1, objs + o * OD, lane);
         }
-        int tick = 0;
-        for (int64_t jb = 0; jb < M; jb += 64) {
-            const int64_t j = jb + lane;
-            const bool valid = j < M;
-            typename SRC::MR m;
-            src.load_model(j, m);
+        // tile 0 -> LDS
+        double2 stage[CPT];
 #pragma unroll
-            for (int o = 0; o < TW; ++o) {
-                const double l = src.lnl(ob[o], m, j, valid);
-                if (l != l) { anynan |= 1u << o; if (j == 0) firstnan |= 1u << o; }
-                ms_push(st[o], l);
-                const bool c = l > fmax(st[o].m, best[o]) + lt;       // false for nan / -inf
-                const unsigned long long mask = __ballot(c);
-                if (mask) {                                           // wave-uniform
-                    const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    if (c) { Cand e; e.lnl = l; e.j = (int32_t)j; e.pad = 0; buf[(size_t)o * cap + cnt[o] + pre] = e; }
-                    cnt[o] += __builtin_popcountll(mask);
+        for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(0, ch); }
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
+        __syncthreads();
+        int tick = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const double* cur = smem + (t & 1) * TD;
+            double* nxt = smem + ((t + 1) & 1) * TD;
+            const bool more = t + 1 < ntiles;
+            if (more) {                                           // issue next tile's loads early ...
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
+            }
+            if (work) {
+#pragma unroll 1
+                for (int s = 0; s < TILE / 64; ++s) {
+                    const int j = t * TILE + s * 64 + lane;
+                    const bool valid = j < M;
+                    typename SRC::MR m;
+                    src.load_model_lds(cur, s * 64 + lane, m);
+#pragma unroll
+                    for (int o = 0; o < TW; ++o) {
+                        typename SRC::OR ob;
+                        src.load_obj_lds(objs + o * OD, ob);
+                        const double l = src.lnl(ob, m, j, valid);
+                        if (l != l) { anynan |= 1u << o; if (j == 0) firstnan |= 1u << o; }
+                        ms_push(st[o], l, tb);
+                        const bool c = l > st[o].m + lt;                      // false for nan / -inf
+                        const unsigned long long mask = __ballot(c);
+                        if (mask) {                                           // wave-uniform
+                            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            if (c) { Cand e; e.lnl = l; e.j = j; e.pad = 0; buf[(size_t)o * cap + cnt[o] + pre] = e; }
+                            cnt[o] += __builtin_popcountll(mask);
+                        }
+                    }
+                    // every 16 steps re-reference each lane's (max, sum) to the wave-wide
+                    // best, so that the candidate filter above works against the best lnl
+                    // any lane has seen (the sum is rescaled accordingly: exact)
+                    if ((++tick & 15) == 0) {
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            const double mx = wave_max(st[o].m);
+                            st[o].s *= exp_neg(st[o].m - mx, tb);
+                            st[o].m = mx;
+                        }
+                    }
                 }
             }
-            if ((++tick & 15) == 0) {
+            if (more) {                                           // ... and park them in the other buffer late
 #pragma unroll
-                for (int o = 0; o < TW; ++o) best[o] = wave_max(st[o].m);
+                for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(nxt)[ch] = stage[q]; }
             }
+            __syncthreads();
         }
-        // the candidate entries were written by other lanes of this wave: make them
-        // visible to this CU's loads (stores drained, vector L1 invalidated)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // per-object max / evidence (wave reductions), parked in LDS so that the PDF
+        // stage below can be ONE loop body instead of TW inlined copies
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const int64_t i = i0 + o;
-            if (i >= N) break;
             const bool fn = __any((firstnan >> o) & 1u);
             const bool an = __any((anynan >> o) & 1u);
-            const MS t = wave_ms(st[o]);
-            const double lm = fn ? (double)NAN : t.m;
-            const double le = an ? (double)NAN : (t.m == INFINITY ? (double)INFINITY : t.m + log(t.s));
-            if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
-            const bool ok = (le - le == 0.0);
-            if (ok) {
-                for (int k = lane; k < kv.acc_stride; k += 64) row[k] = 0.0;
-                const double thr = wt_thresh * exp_neg(t.m - le);
-                const Cand* cb = buf + (size_t)o * cap;
-                const int n = __builtin_amdgcn_readfirstlane(cnt[o]);
-                for (int c0 = 0; c0 < n; c0 += 64) {
-                    const int k = c0 + lane;
-                    const bool in = k < n;
-                    const Cand e = cb[in ? k : 0];
-                    const double w = exp_neg(e.lnl - le);
-                    kde_scatter(kv, row, in && (w > thr), w, e.j, lane);
-                }
+            const double mx = wave_max(st[o].m);
+            const double ss = wave_sum(st[o].s * exp_neg(st[o].m - mx, tb));
+            if (lane == 0) {
+                res[o * 4 + 0] = fn ? (double)NAN : mx;
+                res[o * 4 + 1] = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
+                res[o * 4 + 2] = mx;
+                res[o * 4 + 3] = (double)cnt[o];
             }
-            kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
         }
+        // Tiles are dead from here on; each wave reuses its slice of the LDS as a PDF
+        // row.  The candidate entries were written by other lanes of this wave: make
+        // them visible to this CU's loads (stores drained, vector L1 invalidated).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (work) {
+            const KdeView kv = *kvp;
+#pragma unroll 1
+            for (int o = 0; o < TW; ++o) {
+                const int64_t i = i0 + o;
+                if (i >= N) break;
+                const double lm = res[o * 4 + 0], le = res[o * 4 + 1], mx = res[o * 4 + 2];
+                const int n = __builtin_amdgcn_readfirstlane((int)res[o * 4 + 3]);
+                if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
+                const bool ok = (le - le == 0.0);
+                if (ok) {
+                    for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
+                    const double thr = wt_thresh * exp_neg(mx - le, tb);
+                    const Cand* cb = buf + (size_t)o * cap;
+                    for (int c0 = 0; c0 < n; c0 += 64) {
+                        const int k = c0 + lane;
+                        const bool in = k < n;
+                        const Cand e = cb[in ? k : 0];
+                        const double w = exp_neg(e.lnl - le, tb);
+                        kde_scatter(kv, row, in && (w > thr), w, e.j, lane);
+                    }
+                }
+                kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
+            }
+        }
+        __syncthreads();                                          // rows -> tiles again
     }
 }
 

@@ -68,27 +68,33 @@ int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, c
 
 // single-pass kernel; returns +1 (not an error) when its candidate workspace does
 // not fit the budget and the caller should take the two-pass route
-template <class SRC, int TW>
+template <class SRC, int TW, int NW>
 int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    const size_t per_obj = (size_t)kv.acc_stride * 8;
-    int wpb = 4;
-    while (wpb > 1 && per_obj * wpb > 64 * 1024) wpb >>= 1;
-    if (per_obj * wpb > 160 * 1024) return 1;
+    const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + (size_t)NW * TW * 32 +
+                       (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
+    if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
     const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
-    int64_t waves = std::min<int64_t>(groups, (int64_t)c->cu_count * 8);
-    const int64_t fit = (int64_t)(c->ws_limit / per_wave);
-    if (fit < std::min<int64_t>(groups, (int64_t)c->cu_count * 2)) return 1;     // too few waves to fill the chip
-    waves = std::min(waves, fit);
-    const int64_t blocks = (waves + wpb - 1) / wpb;
-    FZCHK(c->d_cand.ensure((size_t)blocks * wpb * per_wave));
-    const size_t lds = (size_t)wpb * per_obj;
-    auto kern = fz::k_fused<SRC, TW>;
+    const int blocks_per_cu = std::max(1, std::min<int>(16 / NW, (int)((160 * 1024) / lds)));
+    // whole multiples of the CU count (an uneven tail of blocks would idle most CUs)
+    const int64_t need = (groups + NW - 1) / NW;
+    const int64_t fit = (int64_t)(c->ws_limit / (per_wave * NW));
+    int64_t blocks = need;
+    if (need > c->cu_count) {
+        const int64_t k = std::min<int64_t>(blocks_per_cu, fit / c->cu_count);
+        if (k < 1) return 1;                                       // cannot fill the chip
+        blocks = std::min<int64_t>(need, k * c->cu_count);
+    } else if (fit < need) return 1;
+    FZCHK(c->d_cand.ensure((size_t)blocks * NW * per_wave));
+    FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
+    auto kern = fz::k_fused<SRC, TW, NW>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(wpb * 64), lds, c->stream, src, kv, n, M, ko->wt_thresh,
-                       ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
+                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -101,8 +107,8 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
     FZCHK(fz_kde_view(c, kv));
     if (!c->force_twopass) {
         // few objects: one per wave so that the chunk spreads over the chip
-        const int r = (n >= (int64_t)c->cu_count * 16) ? fz_launch_fused_tw<SRC, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs)
-                                                       : fz_launch_fused_tw<SRC, 1>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        const int r = (n >= (int64_t)c->cu_count * 64) ? fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs)
+                                                       : fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         if (r <= 0) return r;
     }
     FZCHK(fz_launch_stats(c, src, n, M, 0, lmap, levid));
