@@ -13,6 +13,7 @@
 
 #include "../../include/frankenz_hip.h"
 #include "fz_device.h"
+#include "fz_knn.h"
 
 // ---- errors ------------------------------------------------------------------
 std::string& fz_err_slot();                       // thread-local, defined in frankenz_hip.hip
@@ -151,13 +152,15 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
 }
 
 // ---- per-band-count launchers (fz_inst.hip, one translation unit per BT) ------
-struct FzKdeArgs;   // fz_launch.h
 #define FZ_DECL_BT(N)                                                                                     \
     int fz_planes_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, double* lnl, double* chi2, \
                         int64_t* ndim, double* scale, double* serr);                                      \
     int fz_fitpredict_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const fz_kde_opts* ko, \
                             double* lmap, double* levid, double* pdfs);                                   \
-    int fz_modec_bt##N(fz_ctx* c, int var, int64_t n, const fz_like_opts* o);
+    int fz_modec_bt##N(fz_ctx* c, int var, int64_t n, const fz_like_opts* o);                             \
+    int fz_knnsubset_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const int64_t* idx, int W, \
+                           const fz_kde_opts* ko, const fz::KnnOut* out, int* errflag);                   \
+    int fz_knnquery_bt##N(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx);
 FZ_DECL_BT(5)
 FZ_DECL_BT(8)
 FZ_DECL_BT(16)

@@ -109,3 +109,44 @@ int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o) {
     return run_modec<FZ_BT, true>(c, n, o);
 #endif
 }
+
+// ---------------------------------------------------------------------------
+// k-NN: brute-force search over the K feature sets and the subset likelihood/PDF
+// ---------------------------------------------------------------------------
+int FZ_NAME(fz_knnquery_bt)(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx) {
+    constexpr int TQ = (FZ_BT == 5) ? 4 : (FZ_BT == 8 ? 2 : 1);
+    const int64_t per = (int64_t)TQ * 4;
+    dim3 grid((unsigned)((n + per - 1) / per), (unsigned)c->knn_K);
+    Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);
+    hipLaunchKernelGGL((k_knn_query<FZ_BT, TQ>), grid, dim3(256), 0, c->stream, c->d_trees.as<float>(), c->Mp, (int)c->knn_M, q, n,
+                       c->knn_F, k, bound2, idx, c->knn_K);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int FZ_NAME(fz_knnsubset_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const int64_t* idx, int W,
+                             const fz_kde_opts* ko, const KnnOut* out, int* errflag) {
+    KdeView kv;
+    memset(&kv, 0, sizeof kv);
+    if (out->pdfs) FZCHK(fz_kde_view(c, kv));
+    else kv.acc_stride = 8;
+    FZCHK(c->d_kv.ensure(sizeof(KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t per_wave = (size_t)kv.acc_stride + FZ_KNN_WMAX + (FZ_KNN_WMAX + 2 * FZ_KNN_HASH) / 2;
+    int wpb = 4;
+    while (wpb > 1 && per_wave * 8 * wpb > 80 * 1024) wpb >>= 1;
+    const size_t lds = per_wave * 8 * wpb;
+    if (lds > 160 * 1024) return fail(-5, "k-NN PDF grid too large for LDS");
+    Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);
+#define FZ_CALL_SUBSET(BT_, MODE_, VAR_)                                                                  \
+    PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
+    auto kern = k_knn_subset<PhotSrc<BT_, MODE_, VAR_>>;                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + wpb - 1) / wpb)), dim3(wpb * 64), lds, c->stream, ph,    \
+                       c->d_kv.as<KdeView>(), kv.acc_stride, n, (int)c->M, idx, W, mode == 2 ? 1 : 0, ko->wt_thresh, \
+                       ko->normalize, *out, errflag);
+    FZ_SWITCH(FZ_CALL_SUBSET)
+    HIPCHK(hipGetLastError());
+    return 0;
+}

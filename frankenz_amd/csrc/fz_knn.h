@@ -1,3 +1,247 @@
-// Monte-Carlo k-NN kernels (knn.py) -- see fz_knn_host.inc for the ABI side.
+// Monte-Carlo k-nearest-neighbour variant (reference frankenz/knn.py).
+//
+//   k_knn_query  : what the K scipy KDTree.query calls of knn.py:834-837 return -- the
+//                  k nearest models (p-norm 2) of every object in each of the K
+//                  Monte-Carlo feature sets -- by exact brute force.
+//   k_knn_subset : knn.py:840-872 for one object per wave: first-appearance de-dup of
+//                  its K*k neighbour row (pandas.unique), likelihood on that subset
+//                  (same arithmetic as the brute-force kernels), logsumexp, weights,
+//                  threshold, kernel stack, normalise.
 #pragma once
 #include "fz_device.h"
+#include "fz_kernels.h"
+
+namespace fz {
+
+// ---------------------------------------------------------------------------
+// exact top-k by streaming: a lane owns one candidate model per step; each of the
+// wave's TQ queries keeps its current k best (distance, index) sorted across lanes
+// 0..k-1 and the k-th distance tau as the admission bar.  After a short warm-up
+// almost no candidate beats tau (expected k*ln(M/k) admissions per query), so the
+// steady state is: FT loads, 2*FT fp64 ops, one compare, one ballot per step.
+// ---------------------------------------------------------------------------
+template <int FT, int TQ>
+__global__ __launch_bounds__(256) void k_knn_query(const float* __restrict__ feats, int64_t Mp, int M,
+                                                   const double* __restrict__ q, int64_t N, int F, int k,
+                                                   double bound2, int64_t* __restrict__ idx, int K) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * TQ;
+    if (i0 >= N) return;
+    const int tree = blockIdx.y;
+    const float* ft = feats + (size_t)tree * FT * Mp;
+    double qv[TQ][FT];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int64_t i = i0 + u < N ? i0 + u : N - 1;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) qv[u][f] = f < F ? q[i * F + f] : 0.0;
+    }
+    double ld[TQ], tau[TQ];
+    int lj[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) { ld[u] = INFINITY; lj[u] = M; tau[u] = bound2; }
+
+    for (int jb = 0; jb < M; jb += 64) {
+        const int j = jb + lane;
+        double p[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) p[f] = (double)ft[(size_t)f * Mp + j];     // Mp padded: always in range
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) { const double d = qv[u][f] - p[f]; d2 = fma(d, d, d2); }
+            unsigned long long mask = __ballot(j < M && d2 < tau[u]);
+            while (mask) {                                   // rare after warm-up
+                const int sl = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double dn = __shfl(d2, sl, 64);
+                if (!(dn < tau[u])) continue;                // bar moved while draining this step
+                const int jn = jb + sl;
+                const int pos = __builtin_popcountll(__ballot(lane < k && ld[u] <= dn));
+                const double ud = __shfl_up(ld[u], 1, 64);
+                const int uj = __shfl_up(lj[u], 1, 64);
+                if (lane > pos) { ld[u] = ud; lj[u] = uj; }
+                else if (lane == pos) { ld[u] = dn; lj[u] = jn; }
+                const double kth = __shfl(ld[u], k - 1, 64);
+                tau[u] = kth < bound2 ? kth : bound2;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int64_t i = i0 + u;
+        if (i < N && lane < k) idx[(i * K + tree) * k + lane] = (ld[u] < bound2) ? lj[u] : M;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// subset likelihood + PDF, one object per wave
+// ---------------------------------------------------------------------------
+#define FZ_KNN_HASH 1024          // open-addressing table slots (>= 2 * W)
+#define FZ_KNN_WMAX 512           // largest K*k handled
+
+struct KnnOut {                    // padded outputs of knn.py:812-821 (any may be NULL)
+    int64_t* neighbors;            // (N,W) -99 padded
+    int64_t* nnbr;                 // (N)
+    double* lnlike; double* chi2; int64_t* ndim; double* scale; double* serr;     // (N,W)
+    double* pdfs; double* lmap; double* levid;
+};
+
+template <class PH>
+__global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __restrict__ kvp, int acc_stride,
+                                                    int64_t N, int M, const int64_t* __restrict__ idx, int W,
+                                                    int free_scale, double wt_thresh, int normalize, KnnOut out,
+                                                    int* __restrict__ errflag) {
+    // LDS per wave (doubles): row[acc_stride] | lnl[WMAX] | then ints: list[WMAX], key[HASH], pos[HASH]
+    extern __shared__ double smem[];
+    PH ph = ph_;
+    ph.tb = global_tabs();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= N) return;
+    const size_t per_wave = (size_t)acc_stride + FZ_KNN_WMAX + (FZ_KNN_WMAX + 2 * FZ_KNN_HASH) / 2;
+    double* row = smem + wave * per_wave;
+    double* lnls = row + acc_stride;
+    int* list = reinterpret_cast<int*>(lnls + FZ_KNN_WMAX);
+    int* hkey = list + FZ_KNN_WMAX;
+    int* hpos = hkey + FZ_KNN_HASH;
+    const KdeView kv = *kvp;
+
+    // ---- pandas.unique: keep first appearances, in order (knn.py:840) ----
+    for (int s = lane; s < FZ_KNN_HASH; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
+    const int64_t* myrow = idx + i * W;
+    bool bad = false;
+    for (int p0 = 0; p0 < W; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < W) {
+            const long long v = myrow[p];
+            if (v < 0 || v >= M) bad = true;          // KDTree's "missing" index: models[M] raises in the reference
+            const int key = (int)v;
+            unsigned h = ((unsigned)key * 2654435761u) >> 22;          // 10 bits
+            while (true) {
+                const int prev = atomicCAS(&hkey[h], -1, key);
+                if (prev == -1 || prev == key) break;
+                h = (h + 1) & (FZ_KNN_HASH - 1);
+            }
+            atomicMin(&hpos[h], p);
+        }
+    }
+    if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+    int nn = 0;                                        // wave-uniform running count
+    for (int p0 = 0; p0 < W; p0 += 64) {
+        const int p = p0 + lane;
+        bool first = false; int key = 0;
+        if (p < W) {
+            key = (int)myrow[p];
+            unsigned h = ((unsigned)key * 2654435761u) >> 22;
+            while (hkey[h] != key) h = (h + 1) & (FZ_KNN_HASH - 1);
+            first = (hpos[h] == p);
+        }
+        const unsigned long long mask = __ballot(first);
+        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (first) list[nn + pre] = key;
+        nn += __builtin_popcountll(mask);
+    }
+    if (out.nnbr && lane == 0) out.nnbr[i] = nn;
+    if (out.neighbors) for (int s = lane; s < W; s += 64) out.neighbors[i * W + s] = s < nn ? list[s] : -99;
+
+    // ---- likelihood on the subset (knn.py:847-849), running max / sum-exp ----
+    typename PH::OR ob;
+    ph.load_obj(i, ob);
+    MS st; ms_init(st);
+    bool isnan0 = false, anynan = false;
+    for (int s0 = 0; s0 < W; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < nn;
+        const int j = in ? list[s] : 0;
+        typename PH::MR m;
+        ph.load_model(j, m);
+        const PairOut r = ph.eval(ob, m);
+        const double l = in ? r.lnl : -INFINITY;
+        if (s < W) {
+            const int64_t o = i * W + s;
+            if (out.lnlike) out.lnlike[o] = in ? r.lnl : -INFINITY;            // knn.py:814-816 padding
+            if (out.chi2) out.chi2[o] = in ? r.chi2 : INFINITY;
+            if (out.ndim) out.ndim[o] = in ? r.ndim : 0;
+            if (out.scale) out.scale[o] = (in && free_scale) ? r.scale : 1.0;
+            if (out.serr) out.serr[o] = (in && free_scale) ? sqrt(1.0 / r.shape) : 0.0;
+            lnls[s] = l;
+        }
+        if (l != l) { anynan = true; if (s == 0) isnan0 = true; }
+        ms_push(st, l, ph.tb);
+    }
+    if (!out.pdfs) return;
+    const bool fn = __any(isnan0), an = __any(anynan);
+    const double mx = wave_max(st.m);
+    const double ss = wave_sum(st.s * exp_neg(st.m - mx, ph.tb));
+    const double lm = fn ? (double)NAN : mx;
+    const double le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
+    if (lane == 0) { if (out.lmap) out.lmap[i] = lm; if (out.levid) out.levid[i] = le; }
+    // ---- weights, threshold, kernel stack (knn.py:862-872) ----
+    const bool ok = (le - le == 0.0);
+    if (ok) {
+        for (int t = lane; t < acc_stride; t += 64) row[t] = 0.0;
+        const double thr = wt_thresh * exp_neg(mx - le, ph.tb);
+        for (int s0 = 0; s0 < nn; s0 += 64) {
+            const int s = s0 + lane;
+            const bool in = s < nn;
+            const double w = exp_neg((in ? lnls[s] : -INFINITY) - le, ph.tb);
+            kde_scatter(kv, row, in && (w > thr), w, in ? list[s] : 0, lane);
+        }
+    }
+    kde_finalize(kv, row, ok, normalize, out.pdfs + i * kv.G, lane);
+}
+
+// NearestNeighbors._predict (knn.py:488-558): PDFs from stored (N,W) ln-weights and
+// the stored neighbour table; one object per wave.
+static __global__ __launch_bounds__(256) void k_knn_predict(const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
+                                                     const double* __restrict__ logwt,
+                                                     const int64_t* __restrict__ nbr, const int64_t* __restrict__ nnbr,
+                                                     int W, double wt_thresh, int normalize, double* __restrict__ pdfs,
+                                                     double* __restrict__ lmap, double* __restrict__ levid,
+                                                     int* __restrict__ errflag) {
+    extern __shared__ double smem[];
+    const FastTabs tb = global_tabs();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= N) return;
+    double* row = smem + (size_t)wave * acc_stride;
+    const KdeView kv = *kvp;
+    const int nn = (int)nnbr[i];
+    if (nn < 0 || nn > W) { if (lane == 0) atomicExch(errflag, 1); return; }
+    MS st; ms_init(st);
+    bool isnan0 = false, anynan = false, bad = false;
+    for (int s0 = 0; s0 < nn; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < nn;
+        const double l = in ? logwt[i * W + s] : -INFINITY;
+        if (in) { const long long j = nbr[i * W + s]; if (j < 0 || j >= M) bad = true; }
+        if (l != l) { anynan = true; if (s == 0) isnan0 = true; }
+        ms_push(st, l, tb);
+    }
+    if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+    const bool fn = __any(isnan0), an = __any(anynan);
+    const double mx = wave_max(st.m);
+    const double ss = wave_sum(st.s * exp_neg(st.m - mx, tb));
+    const double lm = fn ? (double)NAN : mx;
+    const double le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
+    if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
+    const bool ok = (le - le == 0.0);
+    if (ok) {
+        for (int t = lane; t < acc_stride; t += 64) row[t] = 0.0;
+        const double thr = wt_thresh * exp_neg(mx - le, tb);
+        for (int s0 = 0; s0 < nn; s0 += 64) {
+            const int s = s0 + lane;
+            const bool in = s < nn;
+            const double w = exp_neg((in ? logwt[i * W + s] : -INFINITY) - le, tb);
+            kde_scatter(kv, row, in && (w > thr), w, in ? nbr[i * W + s] : 0, lane);
+        }
+    }
+    kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
+}
+
+}  // namespace fz

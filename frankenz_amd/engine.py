@@ -131,6 +131,30 @@ class Engine(object):
         check(self.lib.fz_predict_logwt(self.h, ptr(logwt), n, int(bool(is_log)), C.byref(kopts),
                                         ptr(pdfs), ptr(lmap), ptr(levid)))
 
+    # -- k-NN ------------------------------------------------------------
+    def knn_upload_trees(self, feats):
+        f = np.ascontiguousarray(feats, dtype=np.float32)
+        K, M, F = f.shape
+        check(self.lib.fz_knn_upload_trees(self.h, ptr(f), K, M, F))
+
+    def knn_query(self, q, k, distance_upper_bound, idx, n=None):
+        n = len(q) if n is None else n
+        check(self.lib.fz_knn_query(self.h, ptr(q), n, int(k), float(distance_upper_bound), ptr(idx)))
+
+    def knn_fit_predict(self, x, xe, xm, idx, W, opts, kopts, neighbors=None, nnbr=None, lnlike=None,
+                        chi2=None, ndim=None, scale=None, scale_err=None, pdfs=None, lmap=None,
+                        levid=None, n=None):
+        n = len(x) if n is None else n
+        check(self.lib.fz_knn_fit_predict(self.h, ptr(x), ptr(xe), ptr(xm), n, ptr(idx), int(W),
+                                          C.byref(opts), C.byref(kopts) if kopts is not None else None,
+                                          ptr(neighbors), ptr(nnbr), ptr(lnlike), ptr(chi2), ptr(ndim),
+                                          ptr(scale), ptr(scale_err), ptr(pdfs), ptr(lmap), ptr(levid)))
+
+    def knn_predict_logwt(self, logwt, neighbors, nnbr, W, kopts, pdfs, lmap=None, levid=None, n=None):
+        n = len(logwt) if n is None else n
+        check(self.lib.fz_knn_predict_logwt(self.h, ptr(logwt), ptr(neighbors), ptr(nnbr), n, int(W),
+                                            C.byref(kopts), ptr(pdfs), ptr(lmap), ptr(levid)))
+
     def clean(self, x, xe, xm):
         check(self.lib.fz_clean(self.h, ptr(x), ptr(xe), ptr(xm), x.shape[0], x.shape[1]))
 

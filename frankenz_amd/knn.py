@@ -1,6 +1,305 @@
-"""``NearestNeighbors`` placeholder; implemented in knn.py once the search kernels land."""
+"""
+``NearestNeighbors`` -- drop-in for frankenz/knn.py:33-874 (the Monte-Carlo k-nearest-
+neighbour variant, "KMCkNN") on the GPU.
+
+Reference recipe: K Monte-Carlo realisations of the models -> K KDTrees in feature
+(luptitude) space; per object one Monte-Carlo draw -> k neighbours from each tree ->
+first-appearance union (<= K*k models) -> the usual likelihood / weights / KDE on that
+subset.  Here the K tree queries are replaced by an EXACT brute-force top-k search
+on the GPU (an exact answer satisfies KDTree.query's (1+eps) guarantee; it can differ
+from SciPy's pick only among near-ties within eps), and the subset likelihood + PDF
+stack is one wave per object.  The random draws stay on the host with the caller's
+``numpy.random.RandomState`` so the stream -- and therefore the result -- is the
+reference's.
+"""
+import copy
+import sys
+
+import numpy as np
+
+from . import pdf as _pdf
+from .bruteforce import _check_lprob, _progress
+from .engine import HostObjects, get_engine, kde_opts, like_opts
+
+__all__ = ["NearestNeighbors"]
+
+_GEN_CHUNK = 4096
+
+
+class _FeatureSet(object):
+    """Stand-in for one ``scipy.spatial.KDTree`` of the reference's ``KDTrees`` list:
+    holds the float32 Monte-Carlo feature set (``data``, as the tree would)."""
+
+    def __init__(self, data, leafsize):
+        self.data = data
+        self.n, self.m = data.shape
+        self.leafsize = leafsize
 
 
 class NearestNeighbors():
-    def __init__(self, *a, **k):
-        raise NotImplementedError("NearestNeighbors: HIP k-NN path not built yet")
+    """Fits data and generates predictions using k-nearest neighbours over Monte-Carlo
+    realisations of the models (knn.py:33-38)."""
+
+    def __init__(self, models, models_err, models_mask, leafsize=50, K=25, feature_map='luptitude',
+                 fmap_args=None, fmap_kwargs=None, rstate=None, verbose=True, device=None):
+        self.models = models
+        self.models_err = models_err
+        self.models_mask = models_mask
+        self.NMODEL, self.NDIM = models.shape
+        self.NDATA = None
+        self.fit_lnprior = None
+        self.fit_lnlike = None
+        self.fit_lnprob = None
+        self.fit_Ndim = None
+        self.fit_chi2 = None
+        self.fit_scale = None
+        self.fit_scale_err = None
+        self.leafsize = leafsize
+        self.K = K
+        self.KDTrees = None
+        self.neighbors = None
+        self.Nneighbors = None
+        self.k = None
+        self.eps = None
+        self.p = None
+        self.lp_norm = None
+        self.dbound = None
+        self._device = device
+        if fmap_args is None:
+            fmap_args = []
+        if fmap_kwargs is None:
+            fmap_kwargs = dict()
+        self.fmap_args = fmap_args
+        self.fmap_kwargs = fmap_kwargs
+        if feature_map == 'identity':
+            def feature_map(x, xe, *args, **kwargs):
+                return x, xe
+        elif feature_map == 'magnitude':
+            feature_map = _pdf.magnitude
+        elif feature_map == 'luptitude':
+            feature_map = _pdf.luptitude
+        else:
+            # knn.py:131-140 validates a callable against undefined names and therefore
+            # always ends here
+            raise ValueError("The provided feature map is not valid.")
+        self.feature_map = feature_map
+        if rstate is None:
+            rstate = np.random
+        self.KDTrees = []
+        for i, tree in enumerate(self._train_kdtrees(rstate=rstate)):
+            if verbose:
+                sys.stderr.write("\r{0}/{1} KDTrees constructed".format(i + 1, self.K))
+                sys.stderr.flush()
+            self.KDTrees.append(tree)
+        if verbose:
+            sys.stderr.write("\n")
+            sys.stderr.flush()
+        self._uploaded = False
+
+    def _train_kdtrees(self, rstate=None):
+        """knn.py:158-188: one float32 Monte-Carlo feature set per "tree" (same RNG calls,
+        same float32 roundings as the reference)."""
+        if rstate is None:
+            rstate = np.random
+        for i in range(self.K):
+            models_t = np.array(rstate.normal(self.models, self.models_err), dtype='float32')
+            Y_t, Ye_t = np.array(self.feature_map(models_t, self.models_err, *self.fmap_args,
+                                                  **self.fmap_kwargs), dtype='float32')
+            yield _FeatureSet(Y_t, self.leafsize)
+
+    # ------------------------------------------------------------------
+    def _engine(self):
+        eng = get_engine(self._device)
+        eng.upload_models(self.models, self.models_err, self.models_mask)
+        eng.knn_upload_trees(np.stack([t.data for t in self.KDTrees]))
+        return eng
+
+    def _search_setup(self, k, eps, lp_norm, distance_upper_bound):
+        if lp_norm != 2:
+            raise NotImplementedError("only the Euclidean norm (lp_norm=2) is implemented on the GPU")
+        if k > 64 or self.K * k > 512:
+            raise NotImplementedError("k <= 64 and K*k <= 512 are required (got k=%d, K=%d)" % (k, self.K))
+        self.k = k
+        self.eps = eps              # the search is exact; any eps >= 0 is honoured
+        self.lp_norm = lp_norm
+        self.dbound = distance_upper_bound
+
+    def _query_features(self, data, data_err, rstate):
+        """knn.py:830-832 for every object at once: the (N,B) draw consumes the RNG stream
+        exactly like the reference's per-object draws."""
+        x_t = rstate.normal(data, data_err)
+        y_t, _ = self.feature_map(x_t, data_err, *self.fmap_args, **self.fmap_kwargs)
+        return np.ascontiguousarray(y_t, dtype=np.float64)
+
+    def _alloc_fits(self, Ndata):
+        """knn.py:812-821."""
+        W = self.K * self.k
+        inf = np.inf
+        self.Nneighbors = np.zeros(Ndata, dtype='int')
+        self.neighbors = np.zeros((Ndata, W), dtype='int') - 99
+        self.fit_lnprior = np.zeros((Ndata, W), dtype='float') - inf
+        self.fit_lnlike = np.zeros((Ndata, W), dtype='float') - inf
+        self.fit_lnprob = np.zeros((Ndata, W), dtype='float') - inf
+        self.fit_Ndim = np.zeros((Ndata, W), dtype='int')
+        self.fit_chi2 = np.zeros((Ndata, W), dtype='float') + inf
+        self.fit_scale = np.ones((Ndata, W), dtype='float')
+        self.fit_scale_err = np.zeros((Ndata, W), dtype='float')
+
+    def _run(self, eng, obj, q, lo, hi, opts, ko, track_scale, save_fits, pdfs=None, lmap=None, levid=None):
+        """search + subset likelihood (+ PDFs) for objects [lo,hi)."""
+        n, W = hi - lo, self.K * self.k
+        idx = np.empty((n, W), dtype=np.int64)
+        eng.knn_query(q[lo:hi], self.k, self.dbound, idx, n=n)
+        kw = {}
+        if save_fits:
+            sl = slice(lo, hi)
+            free = bool(opts.free_scale)
+            kw = dict(neighbors=self.neighbors[sl], nnbr=self.Nneighbors[sl], lnlike=self.fit_lnlike[sl],
+                      chi2=self.fit_chi2[sl], ndim=self.fit_Ndim[sl],
+                      scale=self.fit_scale[sl] if (track_scale and free) else None,
+                      scale_err=self.fit_scale_err[sl] if (track_scale and free) else None)
+        eng.knn_fit_predict(obj.x[lo:hi], obj.xe[lo:hi], obj.xm[lo:hi], idx, W, opts, ko, pdfs=pdfs, lmap=lmap,
+                            levid=levid, n=n, **kw)
+        if save_fits:
+            sl = slice(lo, hi)
+            self.fit_lnprob[sl] = self.fit_lnlike[sl]
+            valid = np.arange(W)[None, :] < self.Nneighbors[sl][:, None]
+            self.fit_lnprior[sl] = np.where(valid, 0.0, -np.inf)          # knn.py:852: zeros on the subset
+        return idx
+
+    # ------------------------------------------------------------------
+    def fit(self, data, data_err, data_mask, lprob_func=None, rstate=None, k=20, eps=1e-3, lp_norm=2,
+            distance_upper_bound=np.inf, lprob_args=None, lprob_kwargs=None, track_scale=False, verbose=True):
+        """knn.py:190-279."""
+        _check_lprob(lprob_func, lprob_args)
+        opts = like_opts(lprob_kwargs)
+        if rstate is None:
+            rstate = np.random
+        self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        eng = self._engine()
+        q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
+        obj = HostObjects(data, data_err, data_mask)
+        Ndata = len(obj.x)
+        self.NDATA = Ndata
+        self._alloc_fits(Ndata)
+        self._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True)
+        obj.writeback()
+        _progress(verbose, 'Fitting object', Ndata, Ndata)
+        if verbose:
+            sys.stderr.write('\n')
+            sys.stderr.flush()
+
+    def _fit(self, data, data_err, data_mask, lprob_func=None, rstate=None, lprob_args=None, lprob_kwargs=None,
+             track_scale=False, save_fits=True):
+        """Generator twin (knn.py:281-388): yields ``(idxs, Nidx, results)`` per object;
+        uses the ``k / eps / lp_norm / dbound`` attributes like the reference."""
+        _check_lprob(lprob_func, lprob_args)
+        opts = like_opts(lprob_kwargs)
+        if rstate is None:
+            rstate = np.random
+        self._search_setup(self.k, self.eps, self.lp_norm, self.dbound)
+        eng = self._engine()
+        q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
+        obj = HostObjects(data, data_err, data_mask)
+        Ndata = len(obj.x)
+        self.NDATA = Ndata
+        keep = self if save_fits else copy.copy(self)      # scratch holder when fits are not kept
+        keep._alloc_fits(Ndata)
+        keep._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True)
+        obj.writeback()
+        for i in range(Ndata):
+            n = keep.Nneighbors[i]
+            res = (keep.fit_lnprior[i, :n], keep.fit_lnlike[i, :n], keep.fit_lnprob[i, :n],
+                   keep.fit_Ndim[i, :n], keep.fit_chi2[i, :n])
+            if track_scale:
+                res = res + (keep.fit_scale[i, :n], keep.fit_scale_err[i, :n])
+            yield keep.neighbors[i, :n], n, res
+
+    # ------------------------------------------------------------------
+    def predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, logwt=None,
+                kde_args=None, kde_kwargs=None, return_gof=False, verbose=True):
+        """knn.py:390-486."""
+        if kde_args:
+            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        if logwt is None:
+            logwt = self.fit_lnprob
+        if label_dict is None and label_grid is None:
+            raise ValueError("`label_dict` or `label_grid` must be specified.")
+        if self.fit_lnprob is None and logwt is None:
+            raise ValueError("Fits have not been computed and weights have not been provided.")
+        eng = get_engine(self._device)
+        Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
+        ko = kde_opts(kde_kwargs)
+        Ndata = self.NDATA
+        W = self.neighbors.shape[1]
+        pdfs = np.zeros((Ndata, Nx))
+        lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
+        lw = np.ascontiguousarray(logwt, dtype=np.float64)
+        nb = np.ascontiguousarray(self.neighbors, dtype=np.int64)
+        nn = np.ascontiguousarray(self.Nneighbors, dtype=np.int64)
+        eng.knn_predict_logwt(lw, nb, nn, W, ko, pdfs, lmap, levid, n=Ndata)
+        _progress(verbose, 'Generating PDF', Ndata, Ndata)
+        if verbose:
+            sys.stderr.write('\n')
+            sys.stderr.flush()
+        if return_gof:
+            return pdfs, (lmap, levid)
+        return pdfs
+
+    def _predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, logwt=None,
+                 kde_args=None, kde_kwargs=None):
+        """Generator twin (knn.py:488-558)."""
+        pdfs, (lmap, levid) = self.predict(model_labels, model_label_errs, label_dict=label_dict,
+                                           label_grid=label_grid, logwt=logwt, kde_args=kde_args,
+                                           kde_kwargs=kde_kwargs, return_gof=True, verbose=False)
+        for i in range(len(pdfs)):
+            yield pdfs[i], (lmap[i], levid[i])
+
+    # ------------------------------------------------------------------
+    def fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs, lprob_func=None,
+                    rstate=None, k=20, eps=1e-3, lp_norm=2, distance_upper_bound=np.inf, label_dict=None,
+                    label_grid=None, kde_args=None, kde_kwargs=None, lprob_args=None, lprob_kwargs=None,
+                    return_gof=False, track_scale=False, verbose=True, save_fits=True):
+        """knn.py:560-720."""
+        _check_lprob(lprob_func, lprob_args)
+        if kde_args:
+            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        if label_dict is None and label_grid is None:
+            raise ValueError("`label_dict` or `label_grid` must be specified.")
+        opts = like_opts(lprob_kwargs)
+        ko = kde_opts(kde_kwargs)
+        if rstate is None:
+            rstate = np.random
+        self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        eng = self._engine()
+        Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
+        q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
+        obj = HostObjects(data, data_err, data_mask)
+        Ndata = len(obj.x)
+        pdfs = np.zeros((Ndata, Nx))
+        lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
+        if save_fits:
+            self.NDATA = Ndata
+            self._alloc_fits(Ndata)
+        self._run(eng, obj, q, 0, Ndata, opts, ko, track_scale, save_fits, pdfs, lmap, levid)
+        obj.writeback()
+        _progress(verbose, 'Generating PDF', Ndata, Ndata)
+        if verbose:
+            sys.stderr.write('\n')
+            sys.stderr.flush()
+        if return_gof:
+            return pdfs, (lmap, levid)
+        return pdfs
+
+    def _fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs, lprob_func=None,
+                     rstate=None, label_dict=None, label_grid=None, kde_args=None, kde_kwargs=None,
+                     lprob_args=None, lprob_kwargs=None, track_scale=False, save_fits=True):
+        """Generator twin (knn.py:722-874); uses the ``k / eps / lp_norm / dbound`` attributes."""
+        pdfs, (lmap, levid) = self.fit_predict(
+            data, data_err, data_mask, model_labels, model_label_errs, lprob_func=lprob_func, rstate=rstate,
+            k=self.k, eps=self.eps, lp_norm=self.lp_norm, distance_upper_bound=self.dbound,
+            label_dict=label_dict, label_grid=label_grid, kde_args=kde_args, kde_kwargs=kde_kwargs,
+            lprob_args=lprob_args, lprob_kwargs=lprob_kwargs, return_gof=True, track_scale=track_scale,
+            verbose=False, save_fits=save_fits)
+        for i in range(len(pdfs)):
+            yield pdfs[i], (lmap[i], levid[i])

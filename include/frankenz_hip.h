@@ -133,6 +133,12 @@ int  fz_knn_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t 
                         double* lnlike, double* chi2, int64_t* ndim, double* scale,
                         double* scale_err, double* pdfs, double* lmap, double* levid);
 
+/* NearestNeighbors._predict (knn.py:488-558): PDFs from stored (N,W) ln-weights,
+ * the stored neighbour table (N,W) and counts (N). */
+int  fz_knn_predict_logwt(fz_ctx* ctx, const double* logwt, const int64_t* neighbors,
+                          const int64_t* nnbr, int64_t N, int64_t W, const fz_kde_opts* kde,
+                          double* pdfs, double* lmap, double* levid);
+
 /* diagnostic: evaluate one of the library's device math helpers elementwise
  * (which: 0 v_rcp_f64 seed, 1 / 2 rcp with one / two Newton steps, 3 log_pos,
  * 4 exp_neg).  Used by tests to pin their accuracy against NumPy. */

@@ -1,0 +1,110 @@
+"""NearestNeighbors (knn.py) on the GPU vs the golden vectors (reference + SciPy KDTree)
+and the oracle.  Search parity is defined as in SURVEY 8c: the exact k-NN table must
+equal KDTree.query(eps=0); against the reference default eps=1e-3 everything
+downstream must agree wherever the neighbour sets agree."""
+import numpy as np
+import pytest
+
+import frankenz_oracle as fo
+from conftest import load_golden, SDSS_SIGMA
+
+
+def dicts():
+    from frankenz_amd import PDFDict
+    grid, sg = np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500)
+    return PDFDict(grid, sg), fo.KernelDict(grid, sg)
+
+
+def fkw(fmap):
+    return dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9)) if fmap == 'luptitude' else {}
+
+
+@pytest.mark.parametrize('fmap', ['luptitude', 'identity'])
+def test_mc_feature_sets_bit_exact(fmap):
+    """host side only (no GPU): same RNG stream, same float32 roundings as knn.py:177-184."""
+    from frankenz_amd import NearestNeighbors
+    g = load_golden('g6_knn')
+    nn = NearestNeighbors(g['Y'], g['Ye'], g['Ym'], K=5, feature_map=fmap, fmap_kwargs=fkw(fmap),
+                          rstate=np.random.RandomState(1), verbose=False)
+    assert len(nn.KDTrees) == 5 and nn.KDTrees[0].data.dtype == np.float32
+    np.testing.assert_array_equal(np.stack([t.data for t in nn.KDTrees]), g[fmap + '_feats'])
+    with pytest.raises(ValueError):
+        NearestNeighbors(g['Y'], g['Ye'], g['Ym'], K=1, feature_map=lambda x, xe: (x, xe), verbose=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fmap', ['luptitude', 'identity'])
+def test_g6_knn_golden(fmap):
+    from frankenz_amd import NearestNeighbors
+    g = load_golden('g6_knn')
+    d, _ = dicts()
+    nn = NearestNeighbors(g['Y'], g['Ye'], g['Ym'], K=5, feature_map=fmap, fmap_kwargs=fkw(fmap),
+                          rstate=np.random.RandomState(1), verbose=False)
+    p, (lm, le) = nn.fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['z'], g['ze'],
+                                 rstate=np.random.RandomState(2), k=4, label_dict=d, return_gof=True,
+                                 verbose=False)
+    # exact search == KDTree.query(eps=0), bit for bit, padding included
+    np.testing.assert_array_equal(nn.neighbors, g[fmap + '_neighbors_eps0'])
+    assert nn.neighbors.dtype == g[fmap + '_neighbors_eps0'].dtype
+    np.testing.assert_allclose(p, g[fmap + '_pdfs_eps0'], rtol=1e-9, atol=1e-13)
+    # reference default (eps=1e-3): rows whose neighbour table is identical must agree everywhere
+    rows = np.where((nn.neighbors == g[fmap + '_neighbors']).all(axis=1))[0]
+    assert len(rows) >= len(p) // 2
+    np.testing.assert_array_equal(nn.Nneighbors[rows], g[fmap + '_Nneighbors'][rows])
+    np.testing.assert_allclose(p[rows], g[fmap + '_pdfs'][rows], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(lm[rows], g[fmap + '_lmap'][rows], rtol=1e-10)
+    np.testing.assert_allclose(le[rows], g[fmap + '_levid'][rows], rtol=1e-10)
+    for nm in ('lnprob', 'chi2', 'Ndim'):
+        a, b = getattr(nn, 'fit_' + nm)[rows], g[fmap + '_' + nm][rows]
+        assert a.dtype == b.dtype
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9)
+    # fit() then predict() from the stored table reproduces fit_predict()
+    nn.fit(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), rstate=np.random.RandomState(2), k=4, eps=0.0,
+           verbose=False)
+    np.testing.assert_array_equal(nn.neighbors, g[fmap + '_neighbors_eps0'])
+    p2 = nn.predict(g['z'], g['ze'], label_dict=d, verbose=False)
+    np.testing.assert_allclose(p2, g[fmap + '_pdfs_eps0'], rtol=1e-9, atol=1e-13)
+    rows2 = list(nn._predict(g['z'], g['ze'], label_dict=d))
+    np.testing.assert_allclose(np.array([r[0] for r in rows2]), p2, rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_knn_vs_oracle_larger():
+    """K=25, k=20 (reference defaults) on a 3000-model set; oracle = exact float64 brute force."""
+    from frankenz_amd import NearestNeighbors
+    d, od = dicts()
+    rs = np.random.RandomState(77)
+    M, N, B = 3000, 50, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 30; Ye = 0.03 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS_SIGMA * rs.randn(N, B); Xe = np.tile(SDSS_SIGMA, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.04)
+    kw = fkw('luptitude')
+    nn = NearestNeighbors(Y, Ye, Ym, feature_map='luptitude', fmap_kwargs=kw, rstate=np.random.RandomState(5),
+                          verbose=False)
+    lk = {'free_scale': True, 'ignore_model_err': True}
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6),
+                                 label_dict=d, lprob_kwargs=lk, return_gof=True, track_scale=True, verbose=False)
+    feats = fo.knn_train(Y, Ye, 25, 'luptitude', np.random.RandomState(5), **kw)
+    q = fo.knn_query_features(X, Xe, 'luptitude', np.random.RandomState(6), **kw)
+    tab = fo.knn_neighbors_exact(feats, q, 20)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze,
+                                                     label_dict=od, **lk)
+    np.testing.assert_array_equal(nn.Nneighbors, rnn)
+    np.testing.assert_array_equal(nn.neighbors, rn)
+    np.testing.assert_allclose(nn.fit_lnprob, rlnp, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(p, rp, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(le, rle, rtol=1e-10)
+    assert np.all(nn.fit_scale[nn.neighbors >= 0] != 1.0)
+
+
+@pytest.mark.gpu
+def test_knn_upper_bound_raises_like_reference():
+    from frankenz_amd import NearestNeighbors
+    g = load_golden('g6_knn')
+    d, _ = dicts()
+    nn = NearestNeighbors(g['Y'], g['Ye'], g['Ym'], K=3, feature_map='identity', rstate=np.random.RandomState(1),
+                          verbose=False)
+    with pytest.raises(IndexError):      # KDTree returns index Nmodel -> models[idxs] raises (knn.py:847)
+        nn.fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['z'], g['ze'],
+                       rstate=np.random.RandomState(2), k=4, distance_upper_bound=1e-9, label_dict=d,
+                       verbose=False)
