@@ -1,0 +1,92 @@
+"""N>1 path on CPU: two gloo ranks shard the object axis, compute their block with the
+ORACLE standing in for the GPU kernels, and exchange the results with the same
+collective code the GPU path uses (all-gather of PDF rows / all-reduce of the stack)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class OracleBF(object):
+    """BruteForce-shaped adapter around the oracle (CPU stand-in for the HIP path)."""
+
+    def __init__(self, Y, Ye, Ym, kd):
+        self.Y, self.Ye, self.Ym, self.kd = Y, Ye, Ym, kd
+
+    def fit_predict(self, x, xe, xm, z, ze, return_gof=True, verbose=False, **kw):
+        import frankenz_oracle as fo
+        p, lm, le = fo.bruteforce_fit_predict(x, xe, xm, self.Y, self.Ye, self.Ym, z, ze, label_dict=self.kd)
+        return p, (lm, le)
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch.distributed as dist
+    import frankenz_oracle as fo
+    from frankenz_amd import sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rs = np.random.RandomState(3)
+    M, B = 120, 5
+    Y = rs.lognormal(1, 1, (M, B)); Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, n)] + rs.randn(n, B); Xe = np.ones((n, B)); Xm = np.ones((n, B))
+    X[1, 2] = np.nan                                  # exercises the in-place clean on rank 0's block
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    kd = fo.KernelDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    bf = OracleBF(Y, Ye, Ym, kd)
+    full, (lm, le) = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather='pdfs')
+    stack, _ = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather='stack')
+    local, _ = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather=None)
+    ref, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=kd)
+    sl = sharded.shard_slice(n, world, rank)
+    ok = (np.array_equal(full, ref) and np.array_equal(lm, rlm) and np.array_equal(le, rle)
+          and np.allclose(stack, ref.sum(axis=0), rtol=1e-13, atol=0) and np.array_equal(local, ref[sl]))
+    q.put((rank, bool(ok), full.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [10, 11])      # even and ragged split
+def test_two_rank_gloo_shard_and_gather(n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (n, 701) for _, _, shape in res)
+
+
+def test_shard_bounds_cover_and_order():
+    from frankenz_amd.sharded import shard_bounds, shard_slice
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and np.diff(b).max() - np.diff(b).min() <= 1
+            assert sum(shard_slice(n, w, r).stop - shard_slice(n, w, r).start for r in range(w)) == n
+
+
+def test_knn_draws_are_rank_independent():
+    """the replayed per-rank draws concatenate to the single-process stream"""
+    from frankenz_amd.sharded import _Replay, shard_slice
+    rs = np.random.RandomState(9)
+    X = rs.randn(13, 5); Xe = np.abs(rs.randn(13, 5)) + .1
+    one = np.random.RandomState(2).normal(X, Xe)
+    draws = np.random.RandomState(2).normal(X, Xe)
+    parts = [_Replay(draws[shard_slice(13, 3, r)]).normal(X[shard_slice(13, 3, r)], Xe[shard_slice(13, 3, r)])
+             for r in range(3)]
+    assert np.array_equal(np.concatenate(parts), one)
