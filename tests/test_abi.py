@@ -73,5 +73,5 @@ def test_host_semantics_without_gpu():
     assert k.use_wt_thresh == 1 and k.wt_thresh == -np.inf
     assert kde_opts({'wt_thresh': None}).use_wt_thresh == 0
     d = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
-    xi, si = d.fit(np.array([0.005, 0.015, 7.4]), np.array([-1., 0.0069999, 100.]))
-    assert list(xi) == [0, 2, 740] and list(si) == [0, 0, 499]
+    xi, si = d.fit(np.array([0.005, 0.015, 7.4]), np.array([-1., 0.0089999, 100.]))
+    assert list(xi) == [0, 2, 740] and list(si) == [0, 1, 499]
