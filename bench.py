@@ -222,7 +222,8 @@ def main():
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
+                per_eval = json.load(open(prof)).get("k_" + fam, {}).get("hbm_bytes_per_eval")
+                traffic = per_eval * evals_per_launch if per_eval else None     # PMC pass of profiles/, scaled to this launch
             except Exception:
                 traffic = None
         out = {

@@ -3,7 +3,7 @@
 # sys/hip traces).  Writes gpurun_out/pmc_<n>/ and prints per-kernel per-launch sums.
 #   BENCH_ARGS="--mode B" ./tools_pmc.sh
 export TMPDIR=/tmp
-ARGS="--nobj 200000 --nmodel 100000 --steps 1 --warmup 1 --no-cpu ${BENCH_ARGS}"
+ARGS="--nobj ${NOBJ:-262144} --nmodel 100000 --steps 1 --warmup 1 --no-cpu ${BENCH_ARGS}"
 SETS=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
   "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
