@@ -69,7 +69,8 @@ extern "C" int fz_set_workspace_limit(fz_ctx* c, int64_t bytes) {
 // flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1,
 // bit2 = some value is outside the range the reciprocal-based fast arithmetic accepts
 __global__ void k_prep_models(const double* y, const double* ye, const double* ym, int64_t M, int64_t Mp,
-                              int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags) {
+                              int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags,
+                              double* rec0, int rw0, double* rec1, int rw1) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Mp) return;
     uint32_t bt = 0; int fl = 0;
@@ -87,7 +88,11 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
         sy[(int64_t)b * Mp + j] = vy;
         sye2[(int64_t)b * Mp + j] = ve2;
         sye[(int64_t)b * Mp + j] = ve;
+        rec0[j * rw0 + b] = vy; rec0[j * rw0 + BT + b] = ve2;
+        rec1[j * rw1 + b] = vy;
     }
+    for (int b = 2 * BT; b < rw0; ++b) rec0[j * rw0 + b] = 0.0;
+    for (int b = BT; b < rw1; ++b) rec1[j * rw1 + b] = 0.0;
     bits[j] = bt;
     if (fl) atomicOr(flags, fl);
 }
@@ -106,12 +111,15 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     FZCHK(copy_in(c, c->d_rx.p, y, raw)); FZCHK(copy_in(c, c->d_rxe.p, ye, raw)); FZCHK(copy_in(c, c->d_rxm.p, ym, raw));
     FZCHK(c->d_y.ensure((size_t)BT * Mp * 8)); FZCHK(c->d_ye2.ensure((size_t)BT * Mp * 8)); FZCHK(c->d_ye.ensure((size_t)BT * Mp * 8));
     FZCHK(c->d_mbits.ensure((size_t)Mp * 4)); FZCHK(c->d_flags.ensure(64));
+    const int rw0 = fz_rec_width(2 * BT), rw1 = fz_rec_width(BT);
+    FZCHK(c->d_rec0.ensure((size_t)Mp * rw0 * 8)); FZCHK(c->d_rec1.ensure((size_t)Mp * rw1 * 8));
     HIPCHK(hipMemsetAsync(c->d_flags.p, 0, 64, c->stream));
     {
         Timer t(c, &c->tm.ms_other, &c->tm.n_other);
         hipLaunchKernelGGL(k_prep_models, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_rx.as<double>(), c->d_rxe.as<double>(), c->d_rxm.as<double>(), M, Mp, (int)B, BT,
-                           c->d_y.as<double>(), c->d_ye2.as<double>(), c->d_ye.as<double>(), c->d_mbits.as<uint32_t>(), c->d_flags.as<int>());
+                           c->d_y.as<double>(), c->d_ye2.as<double>(), c->d_ye.as<double>(), c->d_mbits.as<uint32_t>(), c->d_flags.as<int>(),
+                           c->d_rec0.as<double>(), rw0, c->d_rec1.as<double>(), rw1);
     }
     HIPCHK(hipGetLastError());
     int fl = 0;

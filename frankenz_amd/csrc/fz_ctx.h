@@ -59,7 +59,7 @@ struct fz_ctx {
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
     bool models_masked = false, models_wild = false;
-    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB;
+    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1;
     // kde dictionary (PDFDict)
     int64_t G = 0, D = 0;
     std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
@@ -80,7 +80,7 @@ struct fz_ctx {
     DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm;
 
     std::vector<DevBuf*> all_bufs() {
-        std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
+        std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
                                   &d_cls, &d_norm, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_kv, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
@@ -124,9 +124,13 @@ inline int copy_out(fz_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     return 0;
 }
 
+// record width (doubles) of the array-of-records model copies: >= nval and 2 mod 4
+inline int fz_rec_width(int nval) { int w = nval; while (w % 4 != 2) ++w; return w; }
+
 // ---- device views ------------------------------------------------------------
 inline fz::ModelView model_view(fz_ctx* c) {
     fz::ModelView v; v.y = c->d_y.as<double>(); v.ye2 = c->d_ye2.as<double>(); v.ye = c->d_ye.as<double>();
+    v.rec0 = c->d_rec0.as<double>(); v.rec1 = c->d_rec1.as<double>();
     v.bits = c->d_mbits.as<uint32_t>(); v.M = c->M; v.Mp = c->Mp; return v;
 }
 inline fz::ObjView obj_view(fz_ctx* c) {

@@ -25,6 +25,11 @@ struct ModelView {
     const double* y;       // [BT][Mp]  model flux
     const double* ye2;     // [BT][Mp]  model error squared
     const double* ye;      // [BT][Mp]  model error (mode C squares scale*ye, pdf.py:201-202)
+    // array-of-records copies for the LDS-tiled kernel: one record per model, a
+    // contiguous tile is a straight copy and a lane reads its record with
+    // conflict-free ds_read_b128 (record sizes are 16 mod 32 bytes)
+    const double* rec0;    // [Mp][rw0]  y[0..BT) ye2[0..BT) pad      (mode A)
+    const double* rec1;    // [Mp][rw1]  y[0..BT) pad                 (modes Ai, B)
     const uint32_t* bits;  // [Mp]      bit b = models_mask[j][b] != 0 (pad bands 0)
     int64_t M, Mp;
 };
@@ -46,10 +51,13 @@ struct LikeParams {
 struct PairOut { double lnl, chi2, scale, shape; int ndim; };
 
 // xlogy(a-1, chi2) - chi2/2 - gammaln(a) - a ln2      (pdf.py:92-93, 228-229)
+// FASTV: the mask-free tame-data variant, where am1 = B/2 - 1 (or (B-1)/2 - 1) with
+// B = 5 is never zero and chi2 is +0, finite or nan.
+template <bool FASTV = false>
 __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg, const FastTabs& tb) {
-    double xl = am1 * log_pos(chi2, tb);
-    if (am1 == 0.0) xl = (chi2 == chi2) ? 0.0 : chi2;      // xlogy(0, y) = 0 unless y is nan
-    return xl - 0.5 * chi2 - lg;
+    double xl = am1 * log_pos_t<FASTV>(chi2, tb);
+    if (!FASTV && am1 == 0.0) xl = (chi2 == chi2) ? 0.0 : chi2;      // xlogy(0, y) = 0 unless y is nan
+    return fma(-0.5, chi2, xl) - lg;
 }
 
 // VAR selects the arithmetic variant of one (BT, MODE) kernel:
@@ -100,10 +108,15 @@ struct Phot {
         if (lane == BT) { dst[2 * BT] = ov.slv[i]; dst[2 * BT + 1] = __hiloint2double(0, MASKED ? (int)ov.bits[i] : -1); }
     }
     __device__ __forceinline__ void load_obj_lds(const double* p, OR& o) const {
+        // p is 16-B aligned and wave-uniform: broadcast ds_read_b128
+        const double2* q = reinterpret_cast<const double2*>(p);
+        double v[OBJ_DOUBLES];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) { o.x[b] = p[b]; o.v[b] = p[BT + b]; }
-        o.slv = p[2 * BT];
-        o.bits = MASKED ? (uint32_t)__double2loint(p[2 * BT + 1]) : 0xffffffffu;
+        for (int k = 0; k < OBJ_DOUBLES / 2; ++k) { const double2 w = q[k]; v[2 * k] = w.x; v[2 * k + 1] = w.y; }
+#pragma unroll
+        for (int b = 0; b < BT; ++b) { o.x[b] = v[b]; o.v[b] = v[BT + b]; }
+        o.slv = v[2 * BT];
+        o.bits = MASKED ? (uint32_t)__double2loint(v[2 * BT + 1]) : 0xffffffffu;
     }
 
     // num/den: one Newton step on v_rcp_f64 (2e-15 relative, tests/test_hip_fastmath.py)
@@ -111,7 +124,11 @@ struct Phot {
         return SAFE ? num / den : num * rcp_nr<1>(den);
     }
 
+    // DPT: 1 / 0 pins dim_prior at compile time (hot loops, which are unswitched on
+    // it), -1 reads it from lp.
+    template <int DPT = -1>
     __device__ __forceinline__ PairOut eval(const OR& o, const MR& m) const {
+        const bool dim_prior = DPT < 0 ? (lp.dim_prior != 0) : (DPT != 0);
         PairOut r;
         uint32_t jb = o.bits & m.bits;
         r.ndim = MASKED ? __popc(jb) : lp.nband;
@@ -137,7 +154,7 @@ struct Phot {
                     else { num = fma(num, v, t * den); den = den * v; }
                 }
                 chi2 = num * rcp_nr<1>(den);
-                if (!lp.dim_prior) {           // uniform branch; log of the product = sum of logs
+                if (!dim_prior) {              // uniform branch; log of the product = sum of logs
                     int e; vprod = frexp(den, &e); vexp = e;
                 }
             } else {
@@ -146,12 +163,12 @@ struct Phot {
                     const double v = o.v[b] + m.ye2[b];
                     const double d = o.x[b] - m.y[b];
                     chi2 = fma(quot(d * d, v), tm[b], chi2);
-                    if (b < lp.nband && !lp.dim_prior) {   // uniform branch
+                    if (b < lp.nband && !dim_prior) {      // uniform branch
                         int e; vprod *= frexp(v, &e); vexp += e;
                     }
                 }
             }
-            if (!lp.dim_prior) slogv = log_pos(vprod, tb) + (double)vexp * FZ_LN2;
+            if (!dim_prior) slogv = log_pos(vprod, tb) + (double)vexp * FZ_LN2;
         } else if (MODE == 1) {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
@@ -190,10 +207,10 @@ struct Phot {
         }
         r.chi2 = chi2;
         const double nd = (double)r.ndim;
-        if (lp.dim_prior) {
+        if (dim_prior) {
             const double a = (MODE == 2) ? 0.5 * (nd - 1.0) : 0.5 * nd;
             const double lg = MASKED ? lp.lgtab[r.ndim] : lp.lg_full;
-            r.lnl = chi2_logpdf(a - 1.0, chi2, lg, tb);
+            r.lnl = chi2_logpdf<VAR == VAR_FAST>(a - 1.0, chi2, lg, tb);
         } else {
             r.lnl = -0.5 * chi2 - 0.5 * (nd * FZ_LN2PI + slogv);
         }
@@ -219,12 +236,13 @@ __device__ __forceinline__ double wave_max(double v) {
 struct MS { double m, s; };
 __device__ __forceinline__ void ms_init(MS& a) { a.m = -INFINITY; a.s = 0.0; }
 // branch-free: d = l - m is nan when l is nan or both are the same infinity, and
-// then e = 0 and nothing changes; l = -inf gives e = 0 as well.
+// then e ~ 0 and nothing changes; l = -inf gives e ~ 0 as well.
 __device__ __forceinline__ void ms_push(MS& a, double l, const FastTabs& tb) {
     const double d = l - a.m;
-    const double e = exp_neg(-fabs(d), tb);     // nan d -> 0: nans are flagged by the caller
+    const double e = exp_neg(-fabs(d), tb);     // nan d -> ~0: nans are flagged by the caller
     const bool up = d > 0.0;
-    a.s = fma(a.s, up ? e : 1.0, up ? 1.0 : e); // up: s*e + 1 ; else: s + e
+    const double s_up = fma(a.s, e, 1.0), s_dn = a.s + e;
+    a.s = up ? s_up : s_dn;
     a.m = up ? l : a.m;
 }
 __device__ __forceinline__ MS ms_merge(const MS& a, const MS& b) {

@@ -43,7 +43,11 @@ __device__ __forceinline__ FastTabs stage_tabs(double* dst, int tid, int nthread
 
 // natural log for finite x > 0 (denormals included); x == 0 -> -inf, x == +inf -> +inf,
 // NaN or x < 0 -> NaN.  |abs error| < 4e-16 + 2e-16*|log x|.
-__device__ __forceinline__ double log_pos(double x, const FastTabs& tb) {
+// TAME = true: the caller guarantees x is +0, a positive finite number or NaN (a chi2
+// of range-checked data); only the x == 0 fix-up is applied, branch-free, so that two
+// independent evaluations stay in one basic block and interleave.
+template <bool TAME>
+__device__ __forceinline__ double log_pos_t(double x, const FastTabs& tb) {
     const double mant = __builtin_amdgcn_frexp_mant(x);          // [0.5,1)
     const int ex = __builtin_amdgcn_frexp_exp(x);
     const unsigned hi = (unsigned)__double2hiint(mant);
@@ -57,22 +61,30 @@ __device__ __forceinline__ double log_pos(double x, const FastTabs& tb) {
     p = fma(r, p, -0.5);
     p = fma(r * r, p, r);
     double l = fma((double)ex, 0.6931471805599453, t.y) + p;
-    // +normal | +denormal is the only class the table path is valid for; anything
-    // else is rare, so the fix-up sits behind a real wave-uniform branch (the empty
-    // asm keeps the compiler from turning it back into selects).
-    const bool ok = __builtin_amdgcn_class(x, 0x180);
-    if (__ballot(!ok) != 0ull) {
-        asm volatile("" ::: "memory");
-        if (!ok) l = (x == 0.0) ? -INFINITY : ((x == INFINITY) ? INFINITY : NAN);
+    if (TAME) {
+        l = (x == 0.0) ? -INFINITY : l;
+    } else {
+        // +normal | +denormal is the only class the table path is valid for; anything
+        // else is rare, so the fix-up sits behind a real wave-uniform branch (the empty
+        // asm keeps the compiler from turning it back into selects).
+        const bool ok = __builtin_amdgcn_class(x, 0x180);
+        if (__ballot(!ok) != 0ull) {
+            asm volatile("" ::: "memory");
+            if (!ok) l = (x == 0.0) ? -INFINITY : ((x == INFINITY) ? INFINITY : NAN);
+        }
     }
     return l;
 }
-__device__ __forceinline__ double log_pos(double x) { return log_pos(x, global_tabs()); }
+__device__ __forceinline__ double log_pos(double x, const FastTabs& tb) { return log_pos_t<false>(x, tb); }
+__device__ __forceinline__ double log_pos(double x) { return log_pos_t<false>(x, global_tabs()); }
 
-// exp(x) for x <= 0 (what the softmax needs); x <= -745.2 -> 0.  NaN input is NOT
-// propagated (callers track NaNs separately).  Relative error < 3e-16.
+// exp(x) for x <= 0 (what the softmax needs).  Arguments below -700 are clamped, i.e.
+// return exp(-700) ~ 1e-304 instead of underflowing towards 0: harmless for sums of
+// weights (callers never rely on an exact 0) and it keeps 2^q a plain exponent-field
+// add instead of an ldexp.  NaN input is NOT propagated (callers track NaNs
+// separately).  Relative error < 3e-16.
 __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
-    x = fmax(x, -800.0);                                         // also maps NaN -> -800
+    x = fmax(x, -700.0);                                         // also maps NaN -> -700
     const double k = rint(x * 92.33248261689366);                // 64/ln2
     double r = fma(k, -0.010830424696249145, x);                 // ln2/64 hi
     r = fma(k, -3.623510646634843e-19, r);                       // ln2/64 lo  (hi+lo good to 1e-35)
@@ -83,7 +95,9 @@ __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
     p = fma(r, p, 0.5);
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
-    return ldexp(t * p, ki >> 6);
+    const double v = t * p;                                      // in [1,2): exponent field 1023
+    // v * 2^q with q = ki >> 6 in [-1010, 0]: add q to the exponent field
+    return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
 }
 __device__ __forceinline__ double exp_neg(double x) { return exp_neg(x, global_tabs()); }
 

@@ -42,31 +42,39 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
         const double l = P::eval(o, m).lnl;       // pad lanes hold benign data; no divergent branch
         return valid ? l : -INFINITY;
     }
+    template <int DPT>
+    __device__ __forceinline__ double lnl_t(const typename P::OR& o, const typename P::MR& m) const {
+        return P::template eval<DPT>(o, m).lnl;
+    }
 
     // ---- LDS-staged model tiles (k_fused) ----
-    // A tile is TILE consecutive models: NARR rows of TILE doubles (y per band, then
-    // ye2 per band in mode A) followed by the TILE mask words.  Every row is a
-    // contiguous, 16-B aligned slice of the SoA arrays, so staging is plain
-    // 16-B-per-lane copies and reading it back is conflict-free ds_read_b64.
+    // A tile is TILE consecutive model RECORDS (y[BT], then ye2[BT] in mode A, padded to
+    // RW doubles) followed by the TILE mask words: a contiguous slice of the record
+    // array, staged with plain 16-B-per-lane copies.  RW*8 is 16 mod 32 bytes, which
+    // makes a wave's ds_read_b128 of 64 consecutive records bank-conflict free.
     static constexpr int TILE = 256;
-    static constexpr int NARR = BT + (MODE == 0 ? BT : 0);
-    static constexpr int TILE_DOUBLES = NARR * TILE + (P::MASKED ? TILE / 2 : 0);
+    static constexpr int NVAL = BT + (MODE == 0 ? BT : 0);
+    static constexpr int RW = NVAL + ((6 - NVAL % 4) % 4);          // smallest width >= NVAL that is 2 mod 4
+    static_assert(RW >= NVAL && RW % 4 == 2, "record width must be 2 mod 4 doubles (16 mod 32 bytes)");
+    static constexpr int TILE_DOUBLES = RW * TILE + (P::MASKED ? TILE / 2 : 0);
     static constexpr int NCHUNK = TILE_DOUBLES / 2;                 // 16-byte chunks
     __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
-        const int a = ch / (TILE / 2), off = ch % (TILE / 2);
-        const double* src;
-        if (a < BT) src = P::mv.y + (int64_t)a * P::mv.Mp + tile * TILE;
-        else if (a < NARR) src = P::mv.ye2 + (int64_t)(a - BT) * P::mv.Mp + tile * TILE;
-        else src = reinterpret_cast<const double*>(P::mv.bits + tile * TILE);      // TILE 4-byte words
-        return reinterpret_cast<const double2*>(src)[off];
+        const double* rec = (MODE == 0) ? P::mv.rec0 : P::mv.rec1;
+        const double* src = (ch < RW * TILE / 2) ? rec + tile * (TILE * RW) + 2 * ch
+                                                 : reinterpret_cast<const double*>(P::mv.bits + tile * TILE) + 2 * (ch - RW * TILE / 2);
+        return *reinterpret_cast<const double2*>(src);
     }
     __device__ __forceinline__ void load_model_lds(const double* t, int k, typename P::MR& m) const {
+        const double2* r = reinterpret_cast<const double2*>(t + k * RW);
+        double v[RW];
+#pragma unroll
+        for (int q = 0; q < RW / 2; ++q) { const double2 w = r[q]; v[2 * q] = w.x; v[2 * q + 1] = w.y; }
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
-            m.y[b] = t[b * TILE + k];
-            if (MODE == 0) m.ye2[b] = t[(BT + b) * TILE + k];
+            m.y[b] = v[b];
+            if (MODE == 0) m.ye2[b] = v[BT + b];
         }
-        m.bits = P::MASKED ? reinterpret_cast<const uint32_t*>(t + NARR * TILE)[k] : 0xffffffffu;
+        m.bits = P::MASKED ? reinterpret_cast<const uint32_t*>(t + RW * TILE)[k] : 0xffffffffu;
     }
 };
 
@@ -303,6 +311,69 @@ struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 s
 // superset of the pairs with wt > wt_thresh * max(wt), because the running best only
 // grows.  The exact test (pdf.py:510 / 591, strict >) is applied afterwards with the
 // final max and evidence, then the kernels are stacked and the PDF normalised.
+
+// per-wave running state of the single-pass kernel
+template <int TW>
+struct FusedState {
+    MS st[TW];
+    int cnt[TW];
+    unsigned firstnan, anynan;
+    int tick;
+};
+
+// One LDS tile (TILE models, 64 per step) against the wave's TW objects.  The work of
+// a step is laid out stage by stage over the objects -- likelihoods, then softmax
+// updates, then candidate appends -- so that the independent per-object chains sit in
+// one basic block and their LDS / transcendental latencies overlap.  DPT pins
+// dim_prior; TAIL = the last, possibly partial tile (only there are lanes masked).
+template <class SRC, int TW, int DPT, bool TAIL>
+__device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
+                                           int jt0, int M, int lane, double lt, Cand* buf, int64_t cap,
+                                           FusedState<TW>& fs) {
+    constexpr int OD = SRC::OBJ_DOUBLES;
+#pragma unroll 1
+    for (int s = 0; s < SRC::TILE / 64; ++s) {
+        const int j = jt0 + s * 64 + lane;
+        typename SRC::MR m;
+        src.load_model_lds(cur, s * 64 + lane, m);
+        double l[TW];
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            typename SRC::OR ob;
+            src.load_obj_lds(objs + o * OD, ob);
+            l[o] = src.template lnl_t<DPT>(ob, m);
+            if (TAIL) l[o] = (j < M) ? l[o] : -INFINITY;
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            if (l[o] != l[o]) { fs.anynan |= 1u << o; if (j == 0) fs.firstnan |= 1u << o; }
+            ms_push(fs.st[o], l[o], tb);
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            const bool c = l[o] > fs.st[o].m + lt;                        // false for nan / -inf
+            const unsigned long long mask = __ballot(c);
+            if (mask) {                                                   // wave-uniform
+                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (c) { Cand e; e.lnl = l[o]; e.j = j; e.pad = 0; buf[(size_t)o * cap + fs.cnt[o] + pre] = e; }
+                fs.cnt[o] += __builtin_popcountll(mask);
+            }
+        }
+        // every 16 steps re-reference each lane's (max, sum) to the wave-wide best, so
+        // that the candidate filter works against the best lnl any lane has seen (the
+        // sum is rescaled accordingly: exact)
+        if ((++fs.tick & 15) == 0) {
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                const double mx = wave_max(fs.st[o].m);
+                fs.st[o].s *= exp_neg(fs.st[o].m - mx, tb);
+                fs.st[o].m = mx;
+            }
+        }
+    }
+}
+
 template <class SRC, int TW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
                                                     int M, double wt_thresh, int normalize,
@@ -324,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     const int64_t ngroups = (N + TW - 1) / TW;
     const int64_t nrounds = (ngroups + nwaves - 1) / nwaves;      // same for every wave: barriers stay aligned
     const int ntiles = (M + TILE - 1) / TILE;
-    const int big = (2 * TD > NW * acc_stride) ? 2 * TD : NW * acc_stride;
+    const int big = (((2 * TD > NW * acc_stride) ? 2 * TD : NW * acc_stride) + 1) & ~1;   // keeps what follows 16-B aligned
     double* row = smem + (size_t)wave * acc_stride;               // valid only outside the model loop
     double* res = smem + big + wave * (TW * 4);                   // {lmap, levid, max, count} per object
     double* tabs = smem + big + NW * TW * 4;
@@ -334,17 +405,17 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
+    const bool dp = src.lp.dim_prior != 0;
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t g = gw + rnd * nwaves;
         const bool work = g < ngroups;                            // wave-uniform
         const int64_t i0 = work ? g * TW : 0;
-        MS st[TW];
-        int cnt[TW];
-        unsigned firstnan = 0, anynan = 0;
+        FusedState<TW> fs;
+        fs.firstnan = 0; fs.anynan = 0; fs.tick = 0;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            ms_init(st[o]); cnt[o] = 0;
+            ms_init(fs.st[o]); fs.cnt[o] = 0;
             src.park_obj(i0 + o < N ? i0 + o : N - 1, objs + o * OD, lane);
         }
         // tile 0 -> LDS
@@ -354,7 +425,6 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
 #pragma unroll
         for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
         __syncthreads();
-        int tick = 0;
         for (int t = 0; t < ntiles; ++t) {
             const double* cur = smem + (t & 1) * TD;
             double* nxt = smem + ((t + 1) & 1) * TD;
@@ -363,40 +433,13 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
             }
-            if (work) {
-#pragma unroll 1
-                for (int s = 0; s < TILE / 64; ++s) {
-                    const int j = t * TILE + s * 64 + lane;
-                    const bool valid = j < M;
-                    typename SRC::MR m;
-                    src.load_model_lds(cur, s * 64 + lane, m);
-#pragma unroll
-                    for (int o = 0; o < TW; ++o) {
-                        typename SRC::OR ob;
-                        src.load_obj_lds(objs + o * OD, ob);
-                        const double l = src.lnl(ob, m, j, valid);
-                        if (l != l) { anynan |= 1u << o; if (j == 0) firstnan |= 1u << o; }
-                        ms_push(st[o], l, tb);
-                        const bool c = l > st[o].m + lt;                      // false for nan / -inf
-                        const unsigned long long mask = __ballot(c);
-                        if (mask) {                                           // wave-uniform
-                            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            if (c) { Cand e; e.lnl = l; e.j = j; e.pad = 0; buf[(size_t)o * cap + cnt[o] + pre] = e; }
-                            cnt[o] += __builtin_popcountll(mask);
-                        }
-                    }
-                    // every 16 steps re-reference each lane's (max, sum) to the wave-wide
-                    // best, so that the candidate filter above works against the best lnl
-                    // any lane has seen (the sum is rescaled accordingly: exact)
-                    if ((++tick & 15) == 0) {
-#pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-                            const double mx = wave_max(st[o].m);
-                            st[o].s *= exp_neg(st[o].m - mx, tb);
-                            st[o].m = mx;
-                        }
-                    }
+            if (work) {                                           // unswitched on (dim_prior, last tile)
+                if (more) {
+                    if (dp) fused_tile<SRC, TW, 1, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                } else {
+                    if (dp) fused_tile<SRC, TW, 1, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 }
             }
             if (more) {                                           // ... and park them in the other buffer late
@@ -409,15 +452,15 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         // stage below can be ONE loop body instead of TW inlined copies
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const bool fn = __any((firstnan >> o) & 1u);
-            const bool an = __any((anynan >> o) & 1u);
-            const double mx = wave_max(st[o].m);
-            const double ss = wave_sum(st[o].s * exp_neg(st[o].m - mx, tb));
+            const bool fn = __any((fs.firstnan >> o) & 1u);
+            const bool an = __any((fs.anynan >> o) & 1u);
+            const double mx = wave_max(fs.st[o].m);
+            const double ss = wave_sum(fs.st[o].s * exp_neg(fs.st[o].m - mx, tb));
             if (lane == 0) {
                 res[o * 4 + 0] = fn ? (double)NAN : mx;
                 res[o * 4 + 1] = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
                 res[o * 4 + 2] = mx;
-                res[o * 4 + 3] = (double)cnt[o];
+                res[o * 4 + 3] = (double)fs.cnt[o];
             }
         }
         // Tiles are dead from here on; each wave reuses its slice of the LDS as a PDF

@@ -71,12 +71,16 @@ int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, c
 template <class SRC, int TW, int NW>
 int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + (size_t)NW * TW * 32 +
+    const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * 32 +
                        (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
     if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
     const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
-    const int blocks_per_cu = std::max(1, std::min<int>(16 / NW, (int)((160 * 1024) / lds)));
+    auto kern = fz::k_fused<SRC, TW, NW>;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks_per_cu = 1;           // resident blocks per CU for this kernel's registers and LDS
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kern, NW * 64, lds));
+    blocks_per_cu = std::max(1, blocks_per_cu);
     // whole multiples of the CU count (an uneven tail of blocks would idle most CUs)
     const int64_t need = (groups + NW - 1) / NW;
     const int64_t fit = (int64_t)(c->ws_limit / (per_wave * NW));
@@ -90,8 +94,6 @@ int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
-    auto kern = fz::k_fused<SRC, TW, NW>;
-    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
                        kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs);
@@ -108,7 +110,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
     if (!c->force_twopass) {
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
-        int tw = (n >= (int64_t)c->cu_count * 64) ? 2 : 1, nw = (tw == 1) ? 4 : 16;
+        int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
         if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
         int r;
         if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);

@@ -121,7 +121,7 @@ static __global__ __launch_bounds__(256) void k_modec_final(ModeCState st, Model
     const int nd = masked ? __popc(obits[i] & mv.bits[j]) : nband;
     double l = st.l[k];
     const double c = st.c[k];
-    if (dim_prior) l = chi2_logpdf(0.5 * ((double)nd - 1.0) - 1.0, c, lgtab[nd], global_tabs());
+    if (dim_prior) l = chi2_logpdf<false>(0.5 * ((double)nd - 1.0) - 1.0, c, lgtab[nd], global_tabs());
     if (lnl) lnl[k] = l;
     if (chi2) chi2[k] = c;
     if (ndim) ndim[k] = nd;
