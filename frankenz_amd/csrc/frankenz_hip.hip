@@ -365,11 +365,12 @@ static int run_fitpredict(fz_ctx* c, int mode, int var, int dp, int64_t n, const
         default: return fz_fitpredict_bt16(c, mode, var, dp, n, ko, lmap, levid, pdfs);
     }
 }
-static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o) {
+static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr = nullptr,
+                     const int64_t* nnb = nullptr, int W = 0) {
     switch (c->BT) {
-        case 5: return fz_modec_bt5(c, var, n, o);
-        case 8: return fz_modec_bt8(c, var, n, o);
-        default: return fz_modec_bt16(c, var, n, o);
+        case 5: return fz_modec_bt5(c, var, n, o, nbr, nnb, W);
+        case 8: return fz_modec_bt8(c, var, n, o, nbr, nnb, W);
+        default: return fz_modec_bt16(c, var, n, o, nbr, nnb, W);
     }
 }
 
@@ -382,13 +383,15 @@ static int check_kde_opts(const fz_kde_opts* ko) {
 }
 
 static int modec_final(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o, double* lnl, double* chi2, int64_t* ndim,
-                       double* scale, double* serr) {
+                       double* scale, double* serr, const int64_t* nbr = nullptr, const int64_t* nnb = nullptr, int W = 0) {
+    SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
+    const int64_t Mloc = nbr ? W : c->M;
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = nullptr; st.firstnan = nullptr; st.active = nullptr; st.nactive = nullptr;
-    const int64_t tot = n * c->M;
+    const int64_t tot = n * Mloc;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
-    hipLaunchKernelGGL(k_modec_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, st, model_view(c),
-                       c->d_obits.as<uint32_t>(), masked ? 1 : 0, c->B, o->dim_prior, c->d_lgB.as<double>(), n, c->M, lnl, chi2,
+    hipLaunchKernelGGL(k_modec_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, st, model_view(c), sub,
+                       c->d_obits.as<uint32_t>(), masked ? 1 : 0, c->B, o->dim_prior, c->d_lgB.as<double>(), n, Mloc, lnl, chi2,
                        ndim, scale, serr);
     HIPCHK(hipGetLastError());
     return 0;

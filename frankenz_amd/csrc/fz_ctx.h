@@ -161,7 +161,8 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
                         int64_t* ndim, double* scale, double* serr);                                      \
     int fz_fitpredict_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const fz_kde_opts* ko, \
                             double* lmap, double* levid, double* pdfs);                                   \
-    int fz_modec_bt##N(fz_ctx* c, int var, int64_t n, const fz_like_opts* o);                             \
+    int fz_modec_bt##N(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr,           \
+                       const int64_t* nnb, int W);                             \
     int fz_knnsubset_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const int64_t* idx, int W, \
                            const fz_kde_opts* ko, const fz::KnnOut* out, int* errflag);                   \
     int fz_knnquery_bt##N(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx);

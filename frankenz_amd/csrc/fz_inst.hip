@@ -67,8 +67,8 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
 // mode C driver on a prepared chunk: leaves converged state in c->d_mc[*]
 // ---------------------------------------------------------------------------
 template <int BT, bool MASKED>
-static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o) {
-    const int64_t M = c->M;
+static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetView& sub) {
+    const int64_t M = sub.nbr ? sub.W : c->M;
     const size_t pl = (size_t)n * M * 8;
     for (int k = 0; k < 4; ++k) FZCHK(c->d_mc[k].ensure(pl));
     FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(n * 4)); FZCHK(c->d_mccnt.ensure(64));
@@ -78,7 +78,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o) {
     HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
     HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
     HIPCHK(hipMemsetAsync(st.active, 0xff, n * 4, c->stream));       // all active (non-zero)
-    ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B;
+    ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B; mc.sub = sub;
     const int64_t tiles = (M + 255) / 256;
     const int64_t nblk = n * tiles;
     if (nblk > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
@@ -101,12 +101,13 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o) {
     return 0;
 }
 
-int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o) {
+int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr, const int64_t* nnb, int W) {
+    SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
 #if FZ_BT == 5
-    return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o) : run_modec<FZ_BT, true>(c, n, o);
+    return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o, sub) : run_modec<FZ_BT, true>(c, n, o, sub);
 #else
     (void)var;
-    return run_modec<FZ_BT, true>(c, n, o);
+    return run_modec<FZ_BT, true>(c, n, o, sub);
 #endif
 }
 

@@ -195,6 +195,57 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
     kde_finalize(kv, row, ok, normalize, out.pdfs + i * kv.G, lane);
 }
 
+// pandas.unique alone (knn.py:840): neighbour table -> first-appearance lists + counts.
+// Used when the likelihood itself runs elsewhere (the iterative mode C).
+static __global__ __launch_bounds__(256) void k_knn_dedup(int64_t N, int M, const int64_t* __restrict__ idx, int W,
+                                                   int64_t* __restrict__ neighbors, int64_t* __restrict__ nnbr,
+                                                   int* __restrict__ errflag) {
+    extern __shared__ double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= N) return;
+    int* list = reinterpret_cast<int*>(smem) + wave * (FZ_KNN_WMAX + 2 * FZ_KNN_HASH);
+    int* hkey = list + FZ_KNN_WMAX;
+    int* hpos = hkey + FZ_KNN_HASH;
+    for (int s = lane; s < FZ_KNN_HASH; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
+    const int64_t* myrow = idx + i * W;
+    bool bad = false;
+    for (int p0 = 0; p0 < W; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < W) {
+            const long long v = myrow[p];
+            if (v < 0 || v >= M) bad = true;
+            const int key = (int)v;
+            unsigned h = ((unsigned)key * 2654435761u) >> 22;
+            while (true) {
+                const int prev = atomicCAS(&hkey[h], -1, key);
+                if (prev == -1 || prev == key) break;
+                h = (h + 1) & (FZ_KNN_HASH - 1);
+            }
+            atomicMin(&hpos[h], p);
+        }
+    }
+    if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+    int nn = 0;
+    for (int p0 = 0; p0 < W; p0 += 64) {
+        const int p = p0 + lane;
+        bool first = false; int key = 0;
+        if (p < W) {
+            key = (int)myrow[p];
+            unsigned h = ((unsigned)key * 2654435761u) >> 22;
+            while (hkey[h] != key) h = (h + 1) & (FZ_KNN_HASH - 1);
+            first = (hpos[h] == p);
+        }
+        const unsigned long long mask = __ballot(first);
+        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (first) list[nn + pre] = key;
+        nn += __builtin_popcountll(mask);
+    }
+    if (lane == 0) nnbr[i] = nn;
+    for (int s = lane; s < W; s += 64) neighbors[i * W + s] = s < nn ? list[s] : -99;
+}
+
 // NearestNeighbors._predict (knn.py:488-558): PDFs from stored (N,W) ln-weights and
 // the stored neighbour table; one object per wave.
 static __global__ __launch_bounds__(256) void k_knn_predict(const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,

@@ -26,16 +26,22 @@ struct ModeCState {
     int* nactive;              // (1)
 };
 
+// Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
+// model nbr[i*W + j], valid while j < nnb[i].
+struct SubsetView { const int64_t* nbr; const int64_t* nnb; int W; };
+
 template <int BT, bool MASKED>
 struct ModeC {
     ModelView mv;
     ObjView ov;       // v = xe^2
     int nband;
+    SubsetView sub;   // sub.nbr == nullptr: all models
 
     // one solve of (scale, chi2, lnl) for variance var_b = xe2_b + (s_prev*ye_b)^2;
     // s_prev = 1 gives the initial pass of pdf.py:171-194.
     __device__ __forceinline__ void solve(int64_t i, int64_t j, double sprev, double& s, double& lnl,
                                           double& chi2, double& shape, int& ndim) const {
+        if (sub.nbr) j = sub.nbr[i * sub.W + j];
         uint32_t jb = MASKED ? (ov.bits[i] & mv.bits[j]) : 0xffffffffu;
         ndim = MASKED ? __popc(jb) : nband;
         double var[BT], y[BT], x[BT], tm[BT];
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_
     const int64_t i = blockIdx.x / tiles;
     const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
     if (!init && !st.active[i]) return;                  // block-uniform
-    const bool valid = j < M;
+    const bool valid = j < M && (!mc.sub.nnb || j < mc.sub.nnb[i]);
     double e = 0.0;
     if (valid) {
         const int64_t k = i * M + j;
@@ -110,7 +116,7 @@ static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
 }
 
 // after convergence: dim prior (pdf.py:226-229) and the output planes
-static __global__ __launch_bounds__(256) void k_modec_final(ModeCState st, ModelView mv, const uint32_t* obits,
+static __global__ __launch_bounds__(256) void k_modec_final(ModeCState st, ModelView mv, SubsetView sub, const uint32_t* obits,
                                                      int masked, int nband, int dim_prior,
                                                      const double* lgtab, int64_t Nc, int64_t M,
                                                      double* lnl, double* chi2, int64_t* ndim,
@@ -118,7 +124,16 @@ static __global__ __launch_bounds__(256) void k_modec_final(ModeCState st, Model
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= Nc * M) return;
     const int64_t i = k / M, j = k % M;
-    const int nd = masked ? __popc(obits[i] & mv.bits[j]) : nband;
+    if (sub.nnb && j >= sub.nnb[i]) {                     // padding of knn.py:812-821
+        if (lnl) lnl[k] = -INFINITY;
+        if (chi2) chi2[k] = INFINITY;
+        if (ndim) ndim[k] = 0;
+        if (scale) scale[k] = 1.0;
+        if (serr) serr[k] = 0.0;
+        return;
+    }
+    const int64_t jm = sub.nbr ? sub.nbr[i * sub.W + j] : j;
+    const int nd = masked ? __popc(obits[i] & mv.bits[jm]) : nband;
     double l = st.l[k];
     const double c = st.c[k];
     if (dim_prior) l = chi2_logpdf<false>(0.5 * ((double)nd - 1.0) - 1.0, c, lgtab[nd], global_tabs());

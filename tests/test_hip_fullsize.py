@@ -1,0 +1,99 @@
+"""Properties that do not need an oracle pass over the whole problem, checked at
+BASELINE-sized inputs on the GPU (configs[1] full size, configs[2] at 1e5 x 1e5):
+normalisation, shard invariance, agreement between the fused and the materialised
+routes, idempotence of the in-place clean, and oracle parity on a random sample."""
+import numpy as np
+import pytest
+
+import frankenz_oracle as fo
+
+pytestmark = pytest.mark.gpu
+SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
+
+
+def problem(n, m, seed=20260101):
+    rs = np.random.RandomState(seed)
+    Y = rs.lognormal(1., 1., size=(m, 5)); Ye = np.tile(SDSS_SIGMA, (m, 1)); Ym = np.ones((m, 5))
+    X = Y[rs.randint(0, m, n)] + SDSS_SIGMA * rs.standard_normal((n, 5))
+    Xe = np.tile(SDSS_SIGMA, (n, 1)); Xm = np.ones((n, 5))
+    return Y, Ye, Ym, X, Xe, Xm, rs.uniform(0, 6, m), np.full(m, 0.05)
+
+
+def dicts():
+    from frankenz_amd import PDFDict
+    grid, sg = np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500)
+    return PDFDict(grid, sg), fo.KernelDict(grid, sg)
+
+
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}])
+def test_config2_fused_properties_and_sample_parity(kw):
+    from frankenz_amd import BruteForce
+    n, m = 100000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
+    d, od = dicts()
+    bf = BruteForce(Y, Ye, Ym)
+    Xc, Xec, Xmc = X.copy(), Xe.copy(), Xm.copy()
+    p, (lm, le) = bf.fit_predict(Xc, Xec, Xmc, z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True,
+                                 save_fits=False, verbose=False)
+    assert p.shape == (n, 701) and np.isfinite(p).all() and (p >= 0).all()
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=0, atol=1e-12)          # normalised
+    assert np.all(le >= lm) and np.all(le <= lm + np.log(m) + 1e-9)            # max <= logsumexp <= max + ln M
+    np.testing.assert_array_equal(Xc, X)                                         # clean data untouched
+    # shard invariance: any block of objects alone gives the same rows, bit for bit
+    sl = slice(31337, 31337 + 5000)
+    p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d,
+                                    lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_array_equal(le2, le[sl])
+    np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)               # LDS float atomics: order may differ
+    # oracle on a random sample of objects against the FULL model set
+    pick = np.random.RandomState(1).choice(n, 24, replace=False)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze,
+                                             label_dict=od, **kw)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
+    np.testing.assert_allclose(le[pick], rle, rtol=1e-9)
+    np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
+
+
+def test_config1_materialised_planes_and_predict_route():
+    """configs[1] at full size (1e5 x 1e4): planes, then predict() from the planes must
+    reproduce the fused route; checksum-of-rows and sample parity against the oracle."""
+    from frankenz_amd import BruteForce
+    n, m = 100000, 10000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, seed=7)
+    d, od = dicts()
+    bf = BruteForce(Y, Ye, Ym)
+    bf.fit(X.copy(), Xe.copy(), Xm.copy(), verbose=False)
+    assert bf.fit_lnlike.shape == (n, m) and bf.fit_Ndim.dtype == np.int64 and (bf.fit_Ndim == 5).all()
+    assert np.all(bf.fit_scale == 1.0) and np.all(bf.fit_scale_err == 0.0) and np.all(bf.fit_lnprior == 0.0)
+    pick = np.random.RandomState(2).choice(n, 16, replace=False)
+    ref = fo.bruteforce_fit(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym)
+    np.testing.assert_allclose(bf.fit_lnlike[pick], ref['lnlike'], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(bf.fit_chi2[pick], ref['chi2'], rtol=1e-10, atol=1e-10)
+    # checksum of checksums: row sums of chi2 against an independent float64 evaluation of
+    # sum_j chi2_ij = sum_b sum_j (x_ib - y_jb)^2 / (xe_ib^2 + ye_jb^2)
+    rows = pick[:4]
+    want = [np.sum((X[i][None, :] - Y) ** 2 / (Xe[i][None, :] ** 2 + Ye ** 2)) for i in rows]
+    np.testing.assert_allclose(bf.fit_chi2[rows].sum(axis=1), want, rtol=1e-11)
+    p_pred, (lm1, le1) = bf.predict(z, ze, label_dict=d, return_gof=True, verbose=False)
+    p_fused, (lm2, le2) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
+                                                            return_gof=True, save_fits=False, verbose=False)
+    np.testing.assert_array_equal(lm1, lm2)
+    np.testing.assert_allclose(le1, le2, rtol=1e-13)
+    np.testing.assert_allclose(p_pred, p_fused, rtol=1e-10, atol=1e-15)
+
+
+def test_clean_is_idempotent_and_matches_reference_rule():
+    from frankenz_amd.engine import get_engine
+    rs = np.random.RandomState(4)
+    n = 200000
+    x = rs.randn(n, 5); xe = rs.randn(n, 5); xm = np.ones((n, 5))
+    x[rs.rand(n, 5) < 0.01] = np.nan; xe[rs.rand(n, 5) < 0.01] = np.inf; x[rs.rand(n, 5) < 0.01] = -np.inf
+    bad = ~(np.isfinite(x) & np.isfinite(xe) & (xe > 0))
+    eng = get_engine()
+    a, b, c = x.copy(), xe.copy(), xm.copy()
+    eng.clean(a, b, c)
+    assert np.all(a[bad] == 0) and np.all(b[bad] == 1) and np.all(c[bad] == 0)
+    np.testing.assert_array_equal(a[~bad], x[~bad]); np.testing.assert_array_equal(b[~bad], xe[~bad])
+    a2, b2, c2 = a.copy(), b.copy(), c.copy()
+    eng.clean(a2, b2, c2)
+    np.testing.assert_array_equal(a2, a); np.testing.assert_array_equal(b2, b); np.testing.assert_array_equal(c2, c)

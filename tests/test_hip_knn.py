@@ -108,3 +108,34 @@ def test_knn_upper_bound_raises_like_reference():
         nn.fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['z'], g['ze'],
                        rstate=np.random.RandomState(2), k=4, distance_upper_bound=1e-9, label_dict=d,
                        verbose=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dp', [True, False])
+def test_knn_mode_c_subset(dp):
+    """free scale WITH model errors on the neighbour subset: the global stop rule now
+    spans the object's <= K*k neighbours (knn.py:847 -> pdf.py:196-223)."""
+    from frankenz_amd import NearestNeighbors
+    d, od = dicts()
+    rs = np.random.RandomState(31)
+    M, N, B = 600, 40, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 10; Ye = Y * rs.uniform(0.01, 0.08, size=(M, B))
+    Ym = np.ones((M, B)); Ym[rs.rand(M) < 0.1, 2] = 0
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .4, N)[:, None] + SDSS_SIGMA * rs.randn(N, B)
+    Xe = np.tile(SDSS_SIGMA, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = rs.uniform(0.02, 0.1, M)
+    nn = NearestNeighbors(Y, Ye, Ym, K=5, feature_map='identity', rstate=np.random.RandomState(5), verbose=False)
+    lk = {'free_scale': True, 'ignore_model_err': False, 'dim_prior': dp}
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=6,
+                                 label_dict=d, lprob_kwargs=dict(lk, return_scale=True), return_gof=True,
+                                 track_scale=True, verbose=False)
+    feats = fo.knn_train(Y, Ye, 5, 'identity', np.random.RandomState(5))
+    q = fo.knn_query_features(X, Xe, 'identity', np.random.RandomState(6))
+    tab = fo.knn_neighbors_exact(feats, q, 6)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze,
+                                                     label_dict=od, **lk)
+    np.testing.assert_array_equal(nn.neighbors, rn)
+    np.testing.assert_allclose(nn.fit_lnprob, rlnp, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(p, rp, rtol=1e-7, atol=1e-13)
+    np.testing.assert_allclose(le, rle, rtol=1e-9)
+    assert np.all(nn.fit_chi2[nn.neighbors < 0] == np.inf) and np.all(nn.fit_scale[nn.neighbors < 0] == 1.0)
