@@ -101,12 +101,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # FZ_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing tests on a 1-GPU box)
+    backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from frankenz_amd import PDFDict
     from frankenz_amd.engine import Engine, kde_opts, like_opts
@@ -126,7 +133,7 @@ def main():
     d_lm = torch.empty(N, dtype=torch.float64, device=dev)
     d_le = torch.empty(N, dtype=torch.float64, device=dev)
     gathered = None
-    if args.gather and world > 1:
+    if args.gather and world > 1 and backend == "nccl":
         gathered = torch.empty((world * N, G), dtype=torch.float64, device=dev)
     opts, ko = like_opts(kw), kde_opts({})
     extra = {}
@@ -175,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = eng.timing()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

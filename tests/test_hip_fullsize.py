@@ -78,7 +78,7 @@ def test_config1_materialised_planes_and_predict_route():
     p_fused, (lm2, le2) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
                                                             return_gof=True, save_fits=False, verbose=False)
     np.testing.assert_array_equal(lm1, lm2)
-    np.testing.assert_allclose(le1, le2, rtol=1e-13)
+    np.testing.assert_allclose(le1, le2, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(p_pred, p_fused, rtol=1e-10, atol=1e-15)
 
 
