@@ -101,4 +101,21 @@ __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
 }
 __device__ __forceinline__ double exp_neg(double x) { return exp_neg(x, global_tabs()); }
 
+// exp(x) with x clamped to [-700, 700] (NaN -> -700): same algorithm, either sign.
+__device__ __forceinline__ double exp_clamped(double x, const FastTabs& tb) {
+    x = fmin(fmax(x, -700.0), 700.0);
+    const double k = rint(x * 92.33248261689366);
+    double r = fma(k, -0.010830424696249145, x);
+    r = fma(k, -3.623510646634843e-19, r);
+    const int ki = (int)k;
+    const double t = tb.expt[ki & 63];
+    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    const double v = t * p;
+    return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
+}
+
 }  // namespace fz
