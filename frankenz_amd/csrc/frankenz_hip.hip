@@ -83,7 +83,7 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
             const double mk = ym[j * B + b];
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
-            if (!(ve2 == 0.0 || (ve2 > 1e-50 && ve2 < 1e50)) || !(fabs(vy) < 1e100)) fl |= 4;
+            if (!(ve2 == 0.0 || (ve2 > 1e-30 && ve2 < 1e30)) || !(fabs(vy) < 1e30)) fl |= 4;
         } else if (j >= M) { vy = 1.0; ve2 = 1.0; ve = 1.0; }
         sy[(int64_t)b * Mp + j] = vy;
         sye2[(int64_t)b * Mp + j] = ve2;
@@ -285,7 +285,7 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
             const double e2 = e * e;
-            if (!(e2 > 1e-50 && e2 < 1e50) || !(fabs(f) < 1e100)) fl |= 4;
+            if (!(e2 > 1e-30 && e2 < 1e30) || !(fabs(f) < 1e30)) fl |= 4;
             sl += log(e2);
             fx = f;
             v = (vmode == 0) ? e2 : 1.0 / e2;

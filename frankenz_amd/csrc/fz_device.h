@@ -61,7 +61,7 @@ __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg
 }
 
 // VAR selects the arithmetic variant of one (BT, MODE) kernel:
-//   0  no masked band anywhere, variances in [1e-50,1e50]: mask-free code, ONE
+//   0  no masked band anywhere, |flux| < 1e30 and variances in [1e-30,1e30]: mask-free code, ONE
 //      reciprocal per pair (the B per-band quotients are summed over a common
 //      denominator), Newton-refined v_rcp_f64
 //   1  masks present (or B padded up to BT), tame variances: per-band masked terms

@@ -25,6 +25,7 @@ namespace fz {
 struct PlaneSrc {
     const double* p; int64_t ld;
     FastTabs tb;
+    static constexpr int WPOW = 0;
     struct MR {};
     struct OR { const double* row; };
     __device__ __forceinline__ void load_model(int64_t, MR&) const {}
@@ -37,6 +38,16 @@ struct PlaneSrc {
 template <int BT, int MODE, int VAR>
 struct PhotSrc : Phot<BT, MODE, VAR> {
     using P = Phot<BT, MODE, VAR>;
+    // With the dimensionality prior and no masks the likelihood is chi2^(WPOW/2) e^(-chi2/2)/C
+    // with a compile-time half-integer power (B = 5: 3/2 for modes A/Ai, 1 for mode B), so
+    // the weight can be formed with a square root instead of a logarithm (k_fused, WM).
+    static constexpr int WPOW = (VAR == VAR_FAST) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
+    __device__ __forceinline__ double chi2_of(const typename P::OR& o, const typename P::MR& m) const {
+        return P::template eval<1>(o, m).chi2;          // the unused ln-like tail is dead code
+    }
+    __device__ __forceinline__ double lnl_of_chi2(double chi2) const {
+        return chi2_logpdf<true>(0.5 * WPOW, chi2, P::lp.lg_full, P::tb);
+    }
     __device__ __forceinline__ double lnl(const typename P::OR& o, const typename P::MR& m,
                                           int64_t, bool valid) const {
         const double l = P::eval(o, m).lnl;       // pad lanes hold benign data; no divergent branch
@@ -374,7 +385,100 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
     }
 }
 
-template <class SRC, int TW, int NW>
+// ---- weight-space variant of the tile step (SRC::WPOW != 0, dim_prior on) ----------
+// w = exp(lnl - ref) = chi2^(WPOW/2) exp(-chi2/2 - lg - ref) is formed directly: one
+// exp, one rsqrt, no log, no selects.  `ref` (wave-uniform per object) is re-based on
+// the wave-wide best every 16 steps, and at once if a pair would overflow the range.
+// Candidates carry chi2; their exact lnl is recomputed in the PDF stage.
+template <int TW>
+struct WState {
+    double ref[TW], kref[TW];      // reference lnl and lg + ref (uniform)
+    double s[TW], wmax[TW];        // per-lane sum and max of w
+    int cnt[TW];
+    int tick;
+};
+
+template <class SRC, int TW>
+__device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o, double newref) {
+    const double f = exp_neg(ws.ref[o] - newref, src.tb);        // ref = -inf: s and wmax are still 0
+    ws.s[o] *= f; ws.wmax[o] *= f;
+    ws.ref[o] = newref; ws.kref[o] = src.lp.lg_full + newref;
+}
+
+template <class SRC, int TW, bool TAIL>
+__device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
+                                             int jt0, int M, int lane, double thrf, Cand* buf, int64_t cap,
+                                             WState<TW>& ws) {
+    constexpr int OD = SRC::OBJ_DOUBLES;
+    constexpr int WP = SRC::WPOW;
+    static_assert(WP == 2 || WP == 3, "weight-space path is built for chi2^1 and chi2^(3/2)");
+#pragma unroll 1
+    for (int s = 0; s < SRC::TILE / 64; ++s) {
+        const int j = jt0 + s * 64 + lane;
+        typename SRC::MR m;
+        src.load_model_lds(cur, s * 64 + lane, m);
+        double c2[TW], t[TW];
+        bool over = false;
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            typename SRC::OR ob;
+            src.load_obj_lds(objs + o * OD, ob);
+            c2[o] = src.chi2_of(ob, m);
+            t[o] = fma(-0.5, c2[o], -ws.kref[o]);
+            over |= t[o] > 550.0;
+        }
+        if (__any(over)) {                    // rare: first step of an object, or the best lnl jumps by > 550
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                if (__any(t[o] > 550.0)) {    // per object, so an object's arithmetic never depends on its wave-mates
+                    double l = src.lnl_of_chi2(c2[o]);
+                    if (TAIL) l = (j < M) ? l : -INFINITY;
+                    const double cand = ws.ref[o] + log_pos(wave_max(ws.wmax[o]), tb);   // -inf while nothing was seen
+                    w_rebase(src, ws, o, fmax(cand, wave_max(l)));
+                    t[o] = fma(-0.5, c2[o], -ws.kref[o]);
+                }
+            }
+        }
+        double w[TW];
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            const double e = exp_clamped(t[o], tb);
+            if (WP == 3) {
+                const double cc = fmax(c2[o], 1e-300);           // chi2 == 0 (self match): w -> 0, no 0*inf
+                const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
+                double sq = cc * y;                              // ~sqrt(cc)
+                const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
+                sq = fma(sq, r, sq);
+                w[o] = (c2[o] * sq) * e;
+            } else {
+                w[o] = c2[o] * e;
+            }
+            if (TAIL) w[o] = (j < M) ? w[o] : 0.0;
+            ws.s[o] += w[o];
+            ws.wmax[o] = fmax(ws.wmax[o], w[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            const bool c = w[o] > ws.wmax[o] * thrf;
+            const unsigned long long mask = __ballot(c);
+            if (mask) {                                                   // wave-uniform
+                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (c) { Cand e; e.lnl = c2[o]; e.j = j; e.pad = 0; buf[(size_t)o * cap + ws.cnt[o] + pre] = e; }
+                ws.cnt[o] += __builtin_popcountll(mask);
+            }
+        }
+        if ((++ws.tick & 15) == 0) {
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                const double wm = wave_max(ws.wmax[o]);
+                if (wm > 0.0) w_rebase(src, ws, o, ws.ref[o] + log_pos(wm, tb));
+            }
+        }
+    }
+}
+
+template <class SRC, int TW, int NW, bool WM>
 __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
                                                     int M, double wt_thresh, int normalize,
                                                     Cand* __restrict__ cand, int64_t cap,
@@ -405,6 +509,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
+    const double thrf = (wt_thresh > 0.0) ? wt_thresh * 0.999000499833375 : 0.0;     // exp(lt)
     const bool dp = src.lp.dim_prior != 0;
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
@@ -412,10 +517,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         const bool work = g < ngroups;                            // wave-uniform
         const int64_t i0 = work ? g * TW : 0;
         FusedState<TW> fs;
-        fs.firstnan = 0; fs.anynan = 0; fs.tick = 0;
+        WState<TW> ws;
+        fs.firstnan = 0; fs.anynan = 0; fs.tick = 0; ws.tick = 0;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            ms_init(fs.st[o]); fs.cnt[o] = 0;
+            if (WM) { ws.ref[o] = -INFINITY; ws.kref[o] = -INFINITY; ws.s[o] = 0.0; ws.wmax[o] = 0.0; ws.cnt[o] = 0; }
+            else { ms_init(fs.st[o]); fs.cnt[o] = 0; }
             src.park_obj(i0 + o < N ? i0 + o : N - 1, objs + o * OD, lane);
         }
         // tile 0 -> LDS
@@ -433,7 +540,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
             }
-            if (work) {                                           // unswitched on (dim_prior, last tile)
+            if (work && WM) {
+                if constexpr (WM) {
+                    if (more) fused_tile_w<SRC, TW, false>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    else fused_tile_w<SRC, TW, true>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                }
+            } else if (work) {                                    // unswitched on (dim_prior, last tile)
                 if (more) {
                     if (dp) fused_tile<SRC, TW, 1, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                     else fused_tile<SRC, TW, 0, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
@@ -452,6 +564,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         // stage below can be ONE loop body instead of TW inlined copies
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
+            if (WM) {
+                const double mx = ws.ref[o] + log_pos(wave_max(ws.wmax[o]), tb);      // refined below from the candidates
+                const double le = ws.ref[o] + log_pos(wave_sum(ws.s[o]), tb);
+                if (lane == 0) { res[o * 4 + 0] = mx; res[o * 4 + 1] = le; res[o * 4 + 2] = mx; res[o * 4 + 3] = (double)ws.cnt[o]; }
+                continue;
+            }
             const bool fn = __any((fs.firstnan >> o) & 1u);
             const bool an = __any((fs.anynan >> o) & 1u);
             const double mx = wave_max(fs.st[o].m);
@@ -476,8 +594,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 if (i >= N) break;
                 const double lm = res[o * 4 + 0], le = res[o * 4 + 1], mx = res[o * 4 + 2];
                 const int n = __builtin_amdgcn_readfirstlane((int)res[o * 4 + 3]);
-                if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
+                if (lane == 0 && !WM) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
                 const bool ok = (le - le == 0.0);
+                double lbest = -INFINITY;                         // WM: exact max lnl, from the candidates
                 if (ok) {
                     for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
                     const double thr = wt_thresh * exp_neg(mx - le, tb);
@@ -486,9 +605,15 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                         const int k = c0 + lane;
                         const bool in = k < n;
                         const Cand e = cb[in ? k : 0];
-                        const double w = exp_neg(e.lnl - le, tb);
+                        double l = e.lnl;
+                        if constexpr (WM) { l = in ? src.lnl_of_chi2(e.lnl) : -INFINITY; lbest = fmax(lbest, l); }
+                        const double w = exp_neg(l - le, tb);
                         kde_scatter(kv, row, in && (w > thr), w, e.j, lane);
                     }
+                }
+                if (WM) {
+                    lbest = wave_max(lbest);
+                    if (lane == 0) { if (lmap) lmap[i] = (n > 0 && ok) ? lbest : lm; if (levid) levid[i] = le; }
                 }
                 kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
             }

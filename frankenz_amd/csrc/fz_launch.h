@@ -68,15 +68,15 @@ int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, c
 
 // single-pass kernel; returns +1 (not an error) when its candidate workspace does
 // not fit the budget and the caller should take the two-pass route
-template <class SRC, int TW, int NW>
-int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+template <class SRC, int TW, int NW, bool WM>
+int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
     const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * 32 +
                        (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
     if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
     const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
-    auto kern = fz::k_fused<SRC, TW, NW>;
+    auto kern = fz::k_fused<SRC, TW, NW, WM>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = 1;           // resident blocks per CU for this kernel's registers and LDS
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kern, NW * 64, lds));
@@ -101,6 +101,18 @@ int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return 0;
 }
 
+// the weight-space kernel body is used when the source allows it and the dimensionality
+// prior is on (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+template <class SRC, int TW, int NW>
+int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                       double* lmap, double* levid, double* pdfs) {
+    if constexpr (SRC::WPOW != 0) {
+        if (src.lp.dim_prior && !getenv("FZ_NO_WSPACE"))
+            return fz_launch_fused_wm<SRC, TW, NW, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+    }
+    return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+}
+
 // fit_predict on a prepared chunk: single pass when possible, else two passes
 template <class SRC>
 int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap,
@@ -111,6 +123,9 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
+        // measured best geometry per kernel body (profiles/README.md): the chi2^(3/2) weight-space
+        // body fits 128 VGPRs and likes 4 waves/SIMD; the others want the 256-VGPR budget
+        if (tw == 4 && SRC::WPOW == 3 && src.lp.dim_prior && !getenv("FZ_NO_WSPACE")) { tw = 2; nw = 16; }
         if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
         int r;
         if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
