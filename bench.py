@@ -90,6 +90,8 @@ def main():
                     help="fit_predict: headline fused path (default). fit: materialising BruteForce.fit "
                          "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). knn: KMCkNN "
                          "search + subset PDFs (configs[3])")
+    ap.add_argument("--mask-frac", type=float, default=0.0,
+                    help="fraction of object bands flagged unobserved (exercises the masked kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -121,6 +123,8 @@ def main():
     kw = MODES[args.mode]
     N, M = args.nobj, args.nmodel
     Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank)
+    if args.mask_frac > 0:
+        Xm[np.random.RandomState(5).rand(*Xm.shape) < args.mask_frac] = 0.0
     pd = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
     G = pd.Ngrid
 
@@ -243,7 +247,8 @@ def main():
                                    "BruteForce.fit_predict(save_fits=False), likelihood mode %s, "
                                    "dict KDE on 701-pt grid" % (N, M, args.mode),
                        "n_obj_per_gpu": N, "n_model": M, "n_band": 5, "mode": args.mode,
-                       "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None)},
+                       "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
+                       "mask_frac": args.mask_frac},
             "pdfs_per_s": float(world) * N * args.steps / dt,
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in

@@ -143,16 +143,32 @@ struct Phot {
             // tot_var = xe^2 + ye^2 ; chi2 = sum_b m (x-y)^2 / tot_var
             double vprod = 1.0; int vexp = 0;
             if (!MASKED) {
-                // sum_b t_b/v_b = n/d with (n,d) <- (n v_b + t_b d, d v_b): one reciprocal
-                double num = 0.0, den = 1.0;
+                // sum_b t_b/v_b over a common denominator: one reciprocal per pair.  Bands are
+                // combined pairwise (a tree, not a chain) to keep the dependency depth low:
+                // (n,d)(a) + (n,d)(b) = (n_a d_b + n_b d_a, d_a d_b)
+                double tn[BT], tv[BT];
 #pragma unroll
                 for (int b = 0; b < BT; ++b) {
-                    const double v = o.v[b] + m.ye2[b];
+                    tv[b] = o.v[b] + m.ye2[b];
                     const double d = o.x[b] - m.y[b];
-                    const double t = d * d;
-                    if (b == 0) { num = t; den = v; }
-                    else { num = fma(num, v, t * den); den = den * v; }
+                    tn[b] = d * d;
                 }
+                int cntb = BT;
+#pragma unroll
+                for (int lvl = 0; lvl < 5; ++lvl) {
+                    if (cntb > 1) {
+                        const int half = cntb / 2;
+#pragma unroll
+                        for (int p = 0; p < half; ++p) {
+                            const double na = tn[2 * p], nb = tn[2 * p + 1], da = tv[2 * p], db = tv[2 * p + 1];
+                            tn[p] = fma(na, db, nb * da);
+                            tv[p] = da * db;
+                        }
+                        if (cntb & 1) { tn[half] = tn[cntb - 1]; tv[half] = tv[cntb - 1]; }
+                        cntb = half + (cntb & 1);
+                    }
+                }
+                const double num = tn[0], den = tv[0];
                 chi2 = num * rcp_nr<1>(den);
                 if (!dim_prior) {              // uniform branch; log of the product = sum of logs
                     int e; vprod = frexp(den, &e); vexp = e;

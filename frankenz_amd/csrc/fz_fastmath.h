@@ -55,11 +55,12 @@ __device__ __forceinline__ double log_pos_t(double x, const FastTabs& tb) {
     const double2 t = tb.logt[idx];
     const double r = fma(mant, t.x, -1.0);                       // |r| <= 2^-8
     // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
-    double p = fma(r, -1.0 / 6.0, 0.2);
-    p = fma(r, p, -0.25);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    p = fma(r * r, p, r);
+    // r + r^2 (-1/2 + r/3 + r^2 (-1/4 + r/5 - r^2/6)), Estrin form
+    const double r2 = r * r;
+    const double q01 = fma(r, 1.0 / 3.0, -0.5);
+    const double q23 = fma(r, 0.2, -0.25);
+    const double q = fma(r2, fma(r2, -1.0 / 6.0, q23), q01);
+    const double p = fma(r2, q, r);
     double l = fma((double)ex, 0.6931471805599453, t.y) + p;
     if (TAME) {
         l = (x == 0.0) ? -INFINITY : l;
@@ -90,11 +91,12 @@ __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
     r = fma(k, -3.623510646634843e-19, r);                       // ln2/64 lo  (hi+lo good to 1e-35)
     const int ki = (int)k;
     const double t = tb.expt[ki & 63];
-    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    p = fma(r, p, 1.0 / 6.0);
-    p = fma(r, p, 0.5);
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
+    // 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120, Estrin form (dependency depth 3)
+    const double r2 = r * r;
+    const double p01 = 1.0 + r;
+    const double p23 = fma(r, 1.0 / 6.0, 0.5);
+    const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    double p = fma(r2, fma(r2, p45, p23), p01);
     const double v = t * p;                                      // in [1,2): exponent field 1023
     // v * 2^q with q = ki >> 6 in [-1010, 0]: add q to the exponent field
     return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
@@ -109,11 +111,12 @@ __device__ __forceinline__ double exp_clamped(double x, const FastTabs& tb) {
     r = fma(k, -3.623510646634843e-19, r);
     const int ki = (int)k;
     const double t = tb.expt[ki & 63];
-    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    p = fma(r, p, 1.0 / 6.0);
-    p = fma(r, p, 0.5);
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
+    // 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120, Estrin form (dependency depth 3)
+    const double r2 = r * r;
+    const double p01 = 1.0 + r;
+    const double p23 = fma(r, 1.0 / 6.0, 0.5);
+    const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    double p = fma(r2, fma(r2, p45, p23), p01);
     const double v = t * p;
     return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
 }

@@ -472,7 +472,10 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
                 const double wm = wave_max(ws.wmax[o]);
-                if (wm > 0.0) w_rebase(src, ws, o, ws.ref[o] + log_pos(wm, tb));
+                if (wm > 0.0) {
+                    w_rebase(src, ws, o, ws.ref[o] + log_pos(wm, tb));
+                    ws.wmax[o] = 1.0;      // every lane now filters against the wave-wide best (w = 1 after the re-base)
+                }
             }
         }
     }
