@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_kde(SRC src_, KdeView kv, int64_t N, in
         for (int o = 0; o < TW; ++o) {
             if (!ok[o]) continue;                                   // wave-uniform
             const double l = src.lnl(ob[o], m, j, valid);
-            const bool cand = valid && (linear ? true : (l > lthr[o]));
+            const bool cand = valid && (linear ? true : (l >= lthr[o]));   // >=: survives absorption of the offset at huge |lnl|
             if (!__any(cand)) continue;                             // wave-uniform
             const double w = linear ? l : exp_neg(l - le[o], src.tb);
             const bool sel = cand && (w > thr[o]);                  // strict, pdf.py:510/591
@@ -362,7 +362,7 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
         }
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const bool c = l[o] > fs.st[o].m + lt;                        // false for nan / -inf
+            const bool c = l[o] >= fs.st[o].m + lt;                       // >=: lt may be absorbed when |lnl| is huge; false for nan
             const unsigned long long mask = __ballot(c);
             if (mask) {                                                   // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),

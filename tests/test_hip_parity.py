@@ -234,3 +234,36 @@ def test_oracle_parity_band_counts(B, kw):
     assert rows.sum() >= 1 and np.isnan(rp[np.isnan(rf['lnlike']).any(axis=1)]).all()
     assert np.isnan(p[np.isnan(bf.fit_lnlike).any(axis=1)]).all()
     close(p[rows], rp[rows], rtol=1e-8, atol=1e-13); close(lm[rows], rlm[rows]); close(le[rows], rle[rows])
+
+
+@pytest.mark.parametrize('kw', [{}, {'dim_prior': False}, {'ignore_model_err': True},
+                                {'free_scale': True, 'ignore_model_err': True}])
+def test_wild_values_take_the_ieee_variant(kw):
+    """zero / huge / infinite variances and fluxes switch the kernels to IEEE division and
+    the fully special-cased log; results must still follow NumPy's inf/nan arithmetic."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(909)
+    M, N, B = 300, 25, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    Ye[3, 1] = np.inf          # infinite model error: that band contributes 0 (or nan in the log-variance sum)
+    Ye[4, :] = 0.0             # exact model
+    Ye[5, 2] = 1e200           # variance overflows to inf
+    Y[6, 0] = 1e160            # chi2 overflows
+    Ym[7, 3] = 0
+    X = Y[rs.choice(np.arange(10, M), N)] + 0.3 * rs.randn(N, B)
+    Xe = np.full((N, B), 0.3); Xm = np.ones((N, B))
+    Xe[2, 1] = 1e-170          # variance underflows towards 0
+    X[3, 4] = 1e40
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    bf = BruteForce(Y, Ye, Ym)
+    with np.errstate(all='ignore'):
+        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                     return_gof=True, verbose=False, save_fits=True)
+        rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
+                                                 label_dict=od, **kw)
+    close(bf.fit_chi2, rf['chi2'], rtol=1e-9, atol=1e-9)
+    close(bf.fit_lnlike, rf['lnlike'], rtol=1e-9, atol=1e-9)
+    close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    close(p, rp, rtol=1e-8, atol=1e-13)
