@@ -46,8 +46,12 @@ int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n
     Timer t(c, &c->tm.ms_planes, &c->tm.n_planes);
 #define FZ_CALL_PLANES(BT_, MODE_, VAR_)                                                                  \
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
-    hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, chi2, \
-                       ndim, scale, serr);
+    if (dim_prior)                                                                                         \
+        hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO, 1>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, \
+                           chi2, ndim, scale, serr);                                                       \
+    else                                                                                                   \
+        hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO, 0>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, \
+                           chi2, ndim, scale, serr);
     FZ_SWITCH(FZ_CALL_PLANES)
     HIPCHK(hipGetLastError());
     return 0;

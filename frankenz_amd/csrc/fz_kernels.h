@@ -90,10 +90,15 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
 };
 
 // ---- materialising fit ------------------------------------------------------
-template <class PH, int TO>
+// A thread owns one model (registers); the block walks TO objects, UNR at a time so that
+// the independent evaluations interleave; rows of the (N,M) planes are written as
+// coalesced 512-B-per-wave stores.
+template <class PH, int TO, int DPT>
 __global__ __launch_bounds__(256) void k_planes(PH ph_, int64_t N, int64_t M, double* __restrict__ lnl,
                                                 double* __restrict__ chi2, int64_t* __restrict__ ndim,
                                                 double* __restrict__ scale, double* __restrict__ serr) {
+    constexpr int UNR = 4;
+    static_assert(TO % UNR == 0, "TO must be a multiple of the unroll");
     PH ph = ph_;
     ph.tb = global_tabs();
     const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x;
@@ -101,19 +106,27 @@ __global__ __launch_bounds__(256) void k_planes(PH ph_, int64_t N, int64_t M, do
     typename PH::MR m;
     ph.load_model(j, m);                       // j < Mp (Mp is a multiple of 256)
     const int64_t i0 = (int64_t)blockIdx.x * TO;
-    for (int o = 0; o < TO; ++o) {
-        const int64_t i = i0 + o;
-        if (i >= N) break;
-        typename PH::OR ob;
-        ph.load_obj(i, ob);
-        PairOut r = ph.eval(ob, m);
-        if (valid) {
-            const int64_t k = i * M + j;
-            if (lnl) lnl[k] = r.lnl;
-            if (chi2) chi2[k] = r.chi2;
-            if (ndim) ndim[k] = r.ndim;
-            if (scale) scale[k] = r.scale;
-            if (serr) serr[k] = sqrt(1.0 / r.shape);      // pdf.py:232
+    for (int o0 = 0; o0 < TO; o0 += UNR) {
+        if (i0 + o0 >= N) break;
+        PairOut r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + o0 + u < N ? i0 + o0 + u : N - 1;
+            typename PH::OR ob;
+            ph.load_obj(i, ob);
+            r[u] = ph.template eval<DPT>(ob, m);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + o0 + u;
+            if (valid && i < N) {
+                const int64_t k = i * M + j;
+                if (lnl) lnl[k] = r[u].lnl;
+                if (chi2) chi2[k] = r[u].chi2;
+                if (ndim) ndim[k] = r[u].ndim;
+                if (scale) scale[k] = r[u].scale;
+                if (serr) serr[k] = sqrt(1.0 / r[u].shape);      // pdf.py:232
+            }
         }
     }
 }
