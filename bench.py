@@ -88,7 +88,7 @@ def cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
     """the same loop on every host core (one process each, the objects split in blocks);
     spawned BEFORE this process touches the GPU."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
+    ncpu = min(os.cpu_count() or 1, 32)             # bounded: start-up of more workers dominates the run
     per = max(1, min(len(X) // ncpu, 4096))
     jobs = [(Y, Ye, Ym, X[i * per:(i + 1) * per], Xe[i * per:(i + 1) * per], Xm[i * per:(i + 1) * per], z, ze, kw,
              budget_s) for i in range(ncpu)]
