@@ -90,7 +90,7 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
         if (k < 1) return 1;                                       // cannot fill the chip
         blocks = std::min<int64_t>(need, k * c->cu_count);
     } else if (fit < need) return 1;
-    FZCHK(c->d_cand.ensure((size_t)blocks * NW * per_wave));
+    if (c->d_cand.ensure((size_t)blocks * NW * per_wave) != 0) return 1;      // no room for the lists: two-pass route
     FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object

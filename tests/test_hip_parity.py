@@ -267,3 +267,31 @@ def test_wild_values_take_the_ieee_variant(kw):
     close(bf.fit_lnlike, rf['lnlike'], rtol=1e-9, atol=1e-9)
     close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
     close(p, rp, rtol=1e-8, atol=1e-13)
+
+
+def test_two_pass_fallback_matches_single_pass():
+    """with no room for the candidate lists the library takes the two-pass kernels
+    (k_stats + k_kde); both routes must give the same PDFs."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(11)
+    M, N, B = 5000, 300, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.5 * rs.randn(N, B); Xe = np.full((N, B), 0.5); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = rs.uniform(0.01, 0.1, M)          # many sigma classes: window-scatter path
+    eng = get_engine()
+    out = {}
+    for name, lim in (('single', 32 << 30), ('two', 1 << 20)):
+        eng.set_workspace_limit(lim)
+        try:
+            out[name] = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
+                                                          return_gof=True, save_fits=False, verbose=False)
+        finally:
+            eng.set_workspace_limit(32 << 30)
+    (p1, (lm1, le1)), (p2, (lm2, le2)) = out['single'], out['two']
+    close(lm1, lm2, rtol=1e-13, atol=0); close(le1, le2, rtol=1e-12, atol=1e-13)
+    close(p1, p2, rtol=1e-10, atol=1e-16)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze,
+                                             label_dict=od)
+    close(p2[:40], rp, rtol=1e-8, atol=1e-14)
