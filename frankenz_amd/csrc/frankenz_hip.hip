@@ -4,6 +4,7 @@
 // are instantiated per band count in fz_inst.hip.
 #include "fz_ctx.h"
 #include "fz_kernels.h"
+#include "fz_cdf.h"
 #include "fz_knn.h"
 #include "fz_launch.h"
 #include "fz_modec.h"
@@ -376,9 +377,38 @@ static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const
 
 static int check_kde_opts(const fz_kde_opts* ko) {
     if (!ko) return fail(-1, "kde options are NULL");
-    if (!ko->use_wt_thresh)
-        return fail(-6, "wt_thresh=None selects the reference's CDF thresholding (pdf.py:513-516 / 593-597), "
-                        "which is not implemented on the device");
+    if (!ko->use_wt_thresh && !(ko->cdf_thresh > 0.0 && ko->cdf_thresh < 1.0))
+        return fail(-4, "cdf_thresh must lie in (0, 1)");
+    return 0;
+}
+
+// CDF-threshold KDE (pdf.py:513-516 / 593-597) from device-resident rows of (ln-)weights
+static int run_cdf(fz_ctx* c, int64_t n, int L, int64_t M, const double* rows, const int64_t* nbr, const int64_t* nnb,
+                   int is_log, const fz_kde_opts* ko, double* dp, double* dm, double* de) {
+    const int64_t savedM = c->M; c->M = M;
+    KdeView kv; const int rc = fz_kde_view(c, kv);
+    c->M = savedM;
+    if (rc) return rc;
+    FZCHK(c->d_kv.ensure(sizeof(KdeView)));
+    FZCHK(copy_in(c, c->d_kv.p, &kv, sizeof(KdeView)));
+    const size_t per_wave = ((size_t)kv.acc_stride + FZ_CDF_MAXK / 2) * 8;
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+    const size_t lds = per_wave * wpb;
+    HIPCHK(hipFuncSetAttribute((const void*)k_kde_cdf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FZCHK(c->d_flags.ensure(64));
+    HIPCHK(hipMemsetAsync(c->d_flags.p, 0, 64, c->stream));
+    {
+        Timer t(c, &c->tm.ms_kde, &c->tm.n_kde);
+        hipLaunchKernelGGL(k_kde_cdf, dim3((unsigned)((n + wpb - 1) / wpb)), dim3(wpb * 64), lds, c->stream,
+                           c->d_kv.as<KdeView>(), kv.acc_stride, n, L, (int)M, rows, nbr, nnb, is_log, ko->cdf_thresh,
+                           ko->normalize, dp, dm, de, c->d_flags.as<int>());
+    }
+    HIPCHK(hipGetLastError());
+    int ef = 0;
+    FZCHK(copy_out(c, &ef, c->d_flags.p, sizeof ef));
+    if (ef == 2) return fail(-5, "CDF thresholding would drop more than %d kernels per object (cdf_thresh * Nmodel too large)", FZ_CDF_MAXK);
+    if (ef) return fail(-3, "neighbour table entry outside [0, Nmodel) or Nneighbors outside [0, K*k]");
     return 0;
 }
 
@@ -456,8 +486,10 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
     const int64_t M = c->M, G = c->G;
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
     const bool pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
+    const bool cdf = !ko->use_wt_thresh;          // reference CDF rule: materialise the chunk's ln-like rows
     int64_t nc = std::min<int64_t>(N, 1 << 18);
     if (mode == 3) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / (M * 8 * 4)));
+    else if (cdf) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / (M * 8)));
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
@@ -472,9 +504,17 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
             FZCHK(run_modec(c, var, n, o));
             double* lpl = c->d_mc[1].as<double>();
             FZCHK(modec_final(c, n, masked, o, lpl, nullptr, nullptr, nullptr, nullptr));   // in place: lnl plane
-            PlaneSrc ps; ps.p = lpl; ps.ld = M;
-            FZCHK(fz_launch_stats(c, ps, n, M, 0, d_lm, d_le));
-            FZCHK(fz_launch_kde(c, ps, n, M, 0, d_lm, d_le, ko, d_pdf));
+            if (cdf) {
+                FZCHK(run_cdf(c, n, (int)M, M, lpl, nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
+            } else {
+                PlaneSrc ps; ps.p = lpl; ps.ld = M;
+                FZCHK(fz_launch_stats(c, ps, n, M, 0, d_lm, d_le));
+                FZCHK(fz_launch_kde(c, ps, n, M, 0, d_lm, d_le, ko, d_pdf));
+            }
+        } else if (cdf) {
+            FZCHK(c->d_pl[0].ensure((size_t)n * M * 8));
+            FZCHK(run_planes(c, mode, var, o->dim_prior, n, c->d_pl[0].as<double>(), nullptr, nullptr, nullptr, nullptr));
+            FZCHK(run_cdf(c, n, (int)M, M, c->d_pl[0].as<double>(), nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
         } else {
             FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));
         }
@@ -513,9 +553,13 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
         if (pdf_dev) d_pdf = pdfs + i0 * G; else { if ((rc = c->d_pdfs.ensure((size_t)n * G * 8))) break; d_pdf = c->d_pdfs.as<double>(); }
         if (lmap && lm_dev) d_lm = lmap + i0; else { if ((rc = c->d_lmap.ensure(n * 8))) break; d_lm = c->d_lmap.as<double>(); }
         if (levid && le_dev) d_le = levid + i0; else { if ((rc = c->d_levid.ensure(n * 8))) break; d_le = c->d_levid.as<double>(); }
-        PlaneSrc ps; ps.p = d_in; ps.ld = M;
-        if ((rc = fz_launch_stats(c, ps, n, M, linear, d_lm, d_le))) break;
-        if ((rc = fz_launch_kde(c, ps, n, M, linear, d_lm, d_le, ko, d_pdf))) break;
+        if (!ko->use_wt_thresh) {
+            if ((rc = run_cdf(c, n, (int)M, M, d_in, nullptr, nullptr, is_log ? 1 : 0, ko, d_pdf, d_lm, d_le))) break;
+        } else {
+            PlaneSrc ps; ps.p = d_in; ps.ld = M;
+            if ((rc = fz_launch_stats(c, ps, n, M, linear, d_lm, d_le))) break;
+            if ((rc = fz_launch_kde(c, ps, n, M, linear, d_lm, d_le, ko, d_pdf))) break;
+        }
         if (!pdf_dev && (rc = copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8))) break;
         if (lmap && !lm_dev && (rc = copy_out(c, lmap + i0, d_lm, n * 8))) break;
         if (levid && !le_dev && is_log && (rc = copy_out(c, levid + i0, d_le, n * 8))) break;

@@ -1,0 +1,122 @@
+// The reference's CDF thresholding (kde_kwargs wt_thresh=None; pdf.py:513-516, 593-597):
+//
+//     idx_sort = argsort(y_wt); y_cdf = cumsum(y_wt[idx_sort]); y_cdf /= y_cdf[-1]
+//     sel_arr  = idx_sort[y_cdf <= 1 - cdf_thresh]
+//
+// i.e. the ASCENDING prefix whose cumulative weight stays within 1 - cdf_thresh: every
+// kernel is stacked EXCEPT the few largest weights, the minimal top-K whose sum reaches
+// cdf_thresh of the total (K >= 1; K <= cdf_thresh * Ny + 1).  That is a reference quirk
+// (it drops the most probable models), reproduced here as it is: find the top-K by
+// repeated arg-max (K is 1 for any peaked posterior), stack everything else unthresholded.
+// One object per wave, rows of ln-weights or linear weights read from a plane; optional
+// neighbour-table indirection for the k-NN variant.
+#pragma once
+#include "fz_kernels.h"
+
+namespace fz {
+
+#define FZ_CDF_MAXK 64
+
+static __global__ __launch_bounds__(256) void k_kde_cdf(const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int L,
+                                                 int M, const double* __restrict__ rows,
+                                                 const int64_t* __restrict__ nbr, const int64_t* __restrict__ nnb,
+                                                 int is_log, double cdf_thresh, int normalize,
+                                                 double* __restrict__ pdfs, double* __restrict__ lmap,
+                                                 double* __restrict__ levid, int* __restrict__ errflag) {
+    extern __shared__ double smem[];                 // per wave: row[acc_stride] | excl[FZ_CDF_MAXK] ints
+    const FastTabs tb = global_tabs();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= N) return;
+    double* row = smem + (size_t)wave * (acc_stride + FZ_CDF_MAXK / 2);
+    int* excl = reinterpret_cast<int*>(row + acc_stride);
+    const KdeView kv = *kvp;
+    const double* in = rows + i * (int64_t)L;
+    const int n = nnb ? (int)nnb[i] : L;
+    if (n < 0 || n > L) { if (lane == 0) atomicExch(errflag, 1); return; }
+
+    // ---- max / evidence (ln-weights), as bruteforce.py:359-360 ----
+    double le = 0.0;
+    bool ok = true;
+    if (is_log) {
+        MS st; ms_init(st);
+        bool isnan0 = false, anynan = false;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const double l = j < n ? in[j] : -INFINITY;
+            if (l != l) { anynan = true; if (j == 0) isnan0 = true; }
+            ms_push(st, l, tb);
+        }
+        const bool fn = __any(isnan0), an = __any(anynan);
+        const double mx = wave_max(st.m);
+        const double ss = wave_sum(st.s * exp_neg(st.m - mx, tb));
+        le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
+        if (lane == 0) { if (lmap) lmap[i] = fn ? (double)NAN : mx; if (levid) levid[i] = le; }
+        ok = (le - le == 0.0);
+    }
+    // exp_neg clamps at -700 (returns ~1e-304); here an underflowed weight must be an exact 0,
+    // because the rule can leave ONLY such weights selected (pdf = 0/0 = nan in the reference)
+    auto weight = [&](int j) -> double {
+        if (!is_log) return in[j];
+        const double a = in[j] - le;
+        return (a < -700.0) ? 0.0 : exp_neg(a, tb);
+    };
+
+    // ---- total weight and the minimal top-K with sum >= cdf_thresh * total ----
+    int K = 0;
+    bool bad = false;
+    if (ok) {
+        double tot = 0.0;
+        bool wnan = false;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < n) { const double w = weight(j); tot += w; if (w != w) wnan = true; }
+        }
+        tot = wave_sum(tot);
+        if (__any(wnan)) ok = false;                     // nan cdf: nothing is selected (zeros)
+        double excluded = 0.0;
+        while (ok && K < n && (tot - excluded) > (1.0 - cdf_thresh) * tot) {
+            if (K == FZ_CDF_MAXK) { bad = true; break; }
+            double best = -INFINITY; int bj = 0x7fffffff;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < n) {
+                    bool ex = false;
+                    for (int q = 0; q < K; ++q) ex |= (excl[q] == j);
+                    const double w = weight(j);
+                    if (!ex && w > best) { best = w; bj = j; }
+                }
+            }
+            const double wbest = wave_max(best);
+            int cand = (best == wbest) ? bj : 0x7fffffff;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) cand = min(cand, __shfl_xor(cand, s, 64));
+            if (cand == 0x7fffffff) break;               // nothing left (all -inf / empty)
+            if (lane == 0) excl[K] = cand;
+            ++K;
+            excluded += wbest;
+        }
+    }
+    if (bad) { if (lane == 0) atomicExch(errflag, 2); return; }
+
+    // ---- stack every other kernel, unthresholded (pdf.py:599-620 / 519-524) ----
+    for (int t = lane; t < acc_stride; t += 64) row[t] = 0.0;
+    if (ok) {
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool sel = j < n;
+            if (sel) for (int q = 0; q < K; ++q) sel &= (excl[q] != j);
+            const double w = (j < n) ? weight(j) : 0.0;
+            int64_t jm = 0;
+            if (j < n) { jm = nbr ? nbr[i * (int64_t)L + j] : j; if (jm < 0 || jm >= M) { bad = true; jm = 0; sel = false; } }
+            kde_scatter(kv, row, sel, w, jm, lane);
+        }
+    }
+    if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+    // is_log: a non-finite evidence poisons the row (pdf = 0/0) like the reference; linear
+    // weights with a nan give zeros
+    kde_finalize(kv, row, is_log ? ok : true, normalize, pdfs + i * kv.G, lane);
+}
+
+}  // namespace fz

@@ -43,11 +43,12 @@ typedef struct fz_like_opts {
 typedef struct fz_kde_opts {
     double  wt_thresh;     /* relative-amplitude threshold (strict >), 1e-3     */
     int32_t use_wt_thresh; /* 1: wt_thresh rule (pdf.py:507-510 / 589-591).
-                              0: the reference's CDF rule (wt_thresh=None);
-                                 not implemented on the device -> error.
+                              0: the reference's CDF rule (wt_thresh=None,
+                                 pdf.py:513-516 / 593-597) with cdf_thresh.
                               "no thresholding" is wt_thresh=-inf, use=1.       */
     int32_t normalize;     /* 1: pdf /= pdf.sum() (bruteforce.py:370, 629)      */
-    double  cdf_thresh;    /* carried for the error message only                */
+    double  cdf_thresh;    /* CDF rule: keep the ascending prefix with
+                              cdf <= 1 - cdf_thresh (default 2e-4)              */
 } fz_kde_opts;
 
 /* accumulated device time per kernel family since fz_timing_reset (HIP events on

@@ -9,6 +9,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
+SDSS5 = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
 RTOL = 1e-5            # the bar stated in BASELINE.json north_star
 TIGHT = 1e-9           # what fp64 kernels actually achieve on well-conditioned rows
 MODES = [(fs, ime, dp) for fs in (False, True) for ime in (False, True) for dp in (False, True)]
@@ -90,8 +91,12 @@ def test_g4_kde_functions():
     close(hp.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None, cdf_thresh=None), g['kde_nothresh'], atol=1e-14)
     close(hp.gauss_kde(y, ys, grid, y_wt=wt, sig_thresh=3.), g['kde_sig3'], atol=1e-14)
     close(hp.gauss_kde(g['y2'], g['ys2'], grid, y_wt=g['w2']), g['kde_tiny'], atol=1e-14)
-    with pytest.raises(NotImplementedError):       # CDF rule is fenced, loudly
-        hp.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None)
+    # the reference's CDF rule (wt_thresh=None): everything but the minimal top-K is stacked
+    close(hp.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None), g['dict_cdf'], atol=1e-14)
+    close(hp.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None), g['kde_cdf'], atol=1e-14)
+    close(hp.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=0.2),
+          fo.gauss_kde_dict(fo.KernelDict(d.grid, d.sigma_grid), y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=0.2),
+          atol=1e-14)
 
 
 def test_g5_bruteforce_fit_and_predict():
@@ -295,3 +300,36 @@ def test_two_pass_fallback_matches_single_pass():
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od)
     close(p2[:40], rp, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True},
+                                {'free_scale': True, 'ignore_model_err': False}])
+def test_cdf_threshold_rule_through_the_classes(kw):
+    """kde_kwargs={'wt_thresh': None}: BruteForce fused / predict routes and the k-NN variant."""
+    from frankenz_amd import BruteForce, NearestNeighbors
+    d, od = dicts()
+    rs = np.random.RandomState(21)
+    M, N, B = 900, 30, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 5; Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = rs.uniform(0.02, 0.08, M)
+    kk = {'wt_thresh': None, 'cdf_thresh': 0.01}
+    bf = BruteForce(Y, Ye, Ym)
+    p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, kde_kwargs=kk,
+                                 return_gof=True, verbose=False, save_fits=True)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od,
+                                             kde_kwargs=kk, **kw)
+    tol = dict(rtol=1e-7, atol=1e-13)
+    close(p, rp, **tol); close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    close(bf.predict(z, ze, label_dict=d, kde_kwargs=kk, verbose=False), rp, **tol)
+    if kw.get('free_scale') and not kw.get('ignore_model_err'):
+        return
+    nn = NearestNeighbors(Y, Ye, Ym, K=4, feature_map='identity', rstate=np.random.RandomState(5), verbose=False)
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=8,
+                                 label_dict=d, lprob_kwargs=kw, kde_kwargs=kk, return_gof=True, verbose=False)
+    feats = fo.knn_train(Y, Ye, 4, 'identity', np.random.RandomState(5))
+    q = fo.knn_query_features(X, Xe, 'identity', np.random.RandomState(6))
+    tab = fo.knn_neighbors_exact(feats, q, 8)
+    rp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze, label_dict=od, kde_kwargs=kk, **kw)[0]
+    close(p, rp, **tol)
+    close(nn.predict(z, ze, label_dict=d, kde_kwargs=kk, verbose=False), rp, **tol)
