@@ -192,7 +192,7 @@ def main():
             eng.fit(dX, dXe, dXm, opts, d_lnl, d_chi2, n=N)
             return
         if args.workload == "knn":
-            eng.knn_query(dQ, kk, float("inf"), d_idx, n=N)
+            eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
             eng.knn_fit_predict(dX, dXe, dXm, d_idx, Kt * kk, opts, ko, pdfs=d_pdf, lmap=d_lm, levid=d_le, n=N)
             return
         eng.fit_predict(dX, dXe, dXm, opts, ko, d_pdf, d_lm, d_le, n=N)

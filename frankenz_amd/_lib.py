@@ -54,7 +54,7 @@ ABI = {
                                  C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_predict_logwt": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_knn_upload_trees": (C.c_int, [_P, _P, _I32, _I64, _I32]),
-    "fz_knn_query": (C.c_int, [_P, _P, _I64, _I32, _F64, _P]),
+    "fz_knn_query": (C.c_int, [_P, _P, _I64, _I32, _F64, _F64, _P]),
     "fz_selftest_math": (C.c_int, [_P, _I32, _P, _I64, _P]),
     "fz_knn_predict_logwt": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_knn_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),

@@ -23,7 +23,7 @@ namespace fz {
 template <int FT, int TQ>
 __global__ __launch_bounds__(256) void k_knn_query(const float* __restrict__ feats, int64_t Mp, int M,
                                                    const double* __restrict__ q, int64_t N, int F, int k,
-                                                   double bound2, int64_t* __restrict__ idx, int K) {
+                                                   double bound2, int64_t* __restrict__ idx, int K, int pnorm) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * TQ;
@@ -49,9 +49,18 @@ __global__ __launch_bounds__(256) void k_knn_query(const float* __restrict__ fea
         for (int f = 0; f < FT; ++f) p[f] = (double)ft[(size_t)f * Mp + j];     // Mp padded: always in range
 #pragma unroll
         for (int u = 0; u < TQ; ++u) {
+            // pnorm 2: squared Euclidean (bound2 is the squared bound); 1: sum |d|; 0: max |d|
             double d2 = 0.0;
+            if (pnorm == 2) {
 #pragma unroll
-            for (int f = 0; f < FT; ++f) { const double d = qv[u][f] - p[f]; d2 = fma(d, d, d2); }
+                for (int f = 0; f < FT; ++f) { const double d = qv[u][f] - p[f]; d2 = fma(d, d, d2); }
+            } else if (pnorm == 1) {
+#pragma unroll
+                for (int f = 0; f < FT; ++f) d2 += fabs(qv[u][f] - p[f]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < FT; ++f) d2 = fmax(d2, fabs(qv[u][f] - p[f]));
+            }
             unsigned long long mask = __ballot(j < M && d2 < tau[u]);
             while (mask) {                                   // rare after warm-up
                 const int sl = __builtin_ctzll(mask);

@@ -137,9 +137,9 @@ class Engine(object):
         K, M, F = f.shape
         check(self.lib.fz_knn_upload_trees(self.h, ptr(f), K, M, F))
 
-    def knn_query(self, q, k, distance_upper_bound, idx, n=None):
+    def knn_query(self, q, k, distance_upper_bound, idx, n=None, lp_norm=2):
         n = len(q) if n is None else n
-        check(self.lib.fz_knn_query(self.h, ptr(q), n, int(k), float(distance_upper_bound), ptr(idx)))
+        check(self.lib.fz_knn_query(self.h, ptr(q), n, int(k), float(lp_norm), float(distance_upper_bound), ptr(idx)))
 
     def knn_fit_predict(self, x, xe, xm, idx, W, opts, kopts, neighbors=None, nnbr=None, lnlike=None,
                         chi2=None, ndim=None, scale=None, scale_err=None, pdfs=None, lmap=None,

@@ -115,8 +115,8 @@ class NearestNeighbors():
         return eng
 
     def _search_setup(self, k, eps, lp_norm, distance_upper_bound):
-        if lp_norm != 2:
-            raise NotImplementedError("only the Euclidean norm (lp_norm=2) is implemented on the GPU")
+        if lp_norm not in (1, 2, np.inf):
+            raise NotImplementedError("Minkowski norms 1, 2 and inf are implemented on the GPU (got %r)" % (lp_norm,))
         if k > 64 or self.K * k > 512:
             raise NotImplementedError("k <= 64 and K*k <= 512 are required (got k=%d, K=%d)" % (k, self.K))
         self.k = k
@@ -149,7 +149,7 @@ class NearestNeighbors():
         """search + subset likelihood (+ PDFs) for objects [lo,hi)."""
         n, W = hi - lo, self.K * self.k
         idx = np.empty((n, W), dtype=np.int64)
-        eng.knn_query(q[lo:hi], self.k, self.dbound, idx, n=n)
+        eng.knn_query(q[lo:hi], self.k, self.dbound, idx, n=n, lp_norm=self.lp_norm)
         kw = {}
         if save_fits:
             sl = slice(lo, hi)

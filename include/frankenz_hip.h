@@ -120,10 +120,10 @@ int  fz_predict_logwt(fz_ctx* ctx, const double* logwt, int64_t N, int32_t is_lo
 /* ---- Monte-Carlo k-nearest-neighbour variant (knn.py) ---- */
 /* K float32 feature sets (K,M,F) as fed to KDTree (knn.py:177-186). */
 int  fz_knn_upload_trees(fz_ctx* ctx, const float* feats, int32_t K, int64_t M, int32_t F);
-/* exact k-NN of N float64 queries (N,F) in each of the K sets, p-norm 2,
- * the flattened (N,K*k) table of knn.py:834-837; entries beyond
- * distance_upper_bound are M (KDTree's "missing" index). */
-int  fz_knn_query(fz_ctx* ctx, const double* q, int64_t N, int32_t k,
+/* exact k-NN of N float64 queries (N,F) in each of the K sets under the Minkowski
+ * norm lp_norm (1, 2 or inf): the flattened (N,K*k) table of knn.py:834-837;
+ * entries at or beyond distance_upper_bound are M (KDTree's "missing" index). */
+int  fz_knn_query(fz_ctx* ctx, const double* q, int64_t N, int32_t k, double lp_norm,
                   double distance_upper_bound, int64_t* idx);
 /* knn.py:840-872: first-appearance de-dup of each row, likelihood on the subset,
  * weights, KDE.  Outputs padded like knn.py:812-821: neighbors (N,W) with -99,

@@ -139,3 +139,22 @@ def test_knn_mode_c_subset(dp):
     np.testing.assert_allclose(p, rp, rtol=1e-7, atol=1e-13)
     np.testing.assert_allclose(le, rle, rtol=1e-9)
     assert np.all(nn.fit_chi2[nn.neighbors < 0] == np.inf) and np.all(nn.fit_scale[nn.neighbors < 0] == 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', [1, np.inf])
+def test_knn_other_norms_match_scipy(p):
+    """lp_norm = 1 and inf against scipy's KDTree (exact, eps=0) on the same float32 feature sets."""
+    from scipy.spatial import KDTree
+    from frankenz_amd import NearestNeighbors
+    g = load_golden('g6_knn')
+    nn = NearestNeighbors(g['Y'], g['Ye'], g['Ym'], K=3, feature_map='identity', rstate=np.random.RandomState(1),
+                          verbose=False)
+    nn.fit(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), rstate=np.random.RandomState(2), k=5, lp_norm=p,
+           verbose=False)
+    q = np.random.RandomState(2).normal(g['X'], g['Xe'])
+    want = np.concatenate([KDTree(t.data, leafsize=50).query(q, k=5, eps=0, p=p)[1] for t in nn.KDTrees], axis=1)
+    for i in range(len(q)):
+        ids = fo.first_unique(want[i])
+        np.testing.assert_array_equal(nn.neighbors[i, :len(ids)], ids)
+        assert nn.Nneighbors[i] == len(ids)
