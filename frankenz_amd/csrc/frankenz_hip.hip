@@ -98,13 +98,13 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
     if (fl) atomicOr(flags, fl);
 }
 
-static int pick_bt(int B) { return B == 5 ? 5 : (B <= 8 ? 8 : (B <= 16 ? 16 : 0)); }
+static int pick_bt(int B) { return B == 5 ? 5 : (B <= 8 ? 8 : (B <= 16 ? 16 : (B <= 32 ? 32 : 0))); }
 
 extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, const double* ym, int64_t M, int32_t B) {
     if (!c || !y || !ye || !ym) return fail(-1, "fz_models_upload: NULL argument");
     if (M <= 0 || B <= 0) return fail(-1, "fz_models_upload: bad shape (%lld,%d)", (long long)M, B);
     const int BT = pick_bt(B);
-    if (!BT) return fail(-5, "fz_models_upload: %d bands unsupported (max 16)", B);
+    if (!BT) return fail(-5, "fz_models_upload: %d bands unsupported (max 32)", B);
     HIPCHK(hipSetDevice(c->device));
     const int64_t Mp = (M + 255) / 256 * 256;
     const size_t raw = (size_t)M * B * sizeof(double);
@@ -355,7 +355,8 @@ static int run_planes(fz_ctx* c, int mode, int var, int dp, int64_t n, double* l
     switch (c->BT) {
         case 5: return fz_planes_bt5(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
         case 8: return fz_planes_bt8(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
-        default: return fz_planes_bt16(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        case 16: return fz_planes_bt16(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        default: return fz_planes_bt32(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
     }
 }
 static int run_fitpredict(fz_ctx* c, int mode, int var, int dp, int64_t n, const fz_kde_opts* ko, double* lmap, double* levid,
@@ -363,7 +364,8 @@ static int run_fitpredict(fz_ctx* c, int mode, int var, int dp, int64_t n, const
     switch (c->BT) {
         case 5: return fz_fitpredict_bt5(c, mode, var, dp, n, ko, lmap, levid, pdfs);
         case 8: return fz_fitpredict_bt8(c, mode, var, dp, n, ko, lmap, levid, pdfs);
-        default: return fz_fitpredict_bt16(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        case 16: return fz_fitpredict_bt16(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        default: return fz_fitpredict_bt32(c, mode, var, dp, n, ko, lmap, levid, pdfs);
     }
 }
 static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr = nullptr,
@@ -371,7 +373,8 @@ static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const
     switch (c->BT) {
         case 5: return fz_modec_bt5(c, var, n, o, nbr, nnb, W);
         case 8: return fz_modec_bt8(c, var, n, o, nbr, nnb, W);
-        default: return fz_modec_bt16(c, var, n, o, nbr, nnb, W);
+        case 16: return fz_modec_bt16(c, var, n, o, nbr, nnb, W);
+        default: return fz_modec_bt32(c, var, n, o, nbr, nnb, W);
     }
 }
 

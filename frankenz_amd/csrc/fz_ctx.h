@@ -169,4 +169,5 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
 FZ_DECL_BT(5)
 FZ_DECL_BT(8)
 FZ_DECL_BT(16)
+FZ_DECL_BT(32)
 #undef FZ_DECL_BT

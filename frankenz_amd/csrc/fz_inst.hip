@@ -1,7 +1,7 @@
 // Per-band-count instantiations of the photometric kernels.  Compiled once per
 // FZ_BT in {5, 8, 16} (separate translation units so they build in parallel).
 #ifndef FZ_BT
-#error "compile with -DFZ_BT=5|8|16"
+#error "compile with -DFZ_BT=5|8|16|32"
 #endif
 #include "fz_ctx.h"
 #include "fz_kernels.h"
@@ -119,7 +119,7 @@ int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, c
 // k-NN: brute-force search over the K feature sets and the subset likelihood/PDF
 // ---------------------------------------------------------------------------
 int FZ_NAME(fz_knnquery_bt)(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx, int pnorm) {
-    constexpr int TQ = (FZ_BT == 5) ? 4 : (FZ_BT == 8 ? 2 : 1);
+    constexpr int TQ = (FZ_BT == 5) ? 4 : (FZ_BT == 8 ? 2 : 1);     // queries per wave (register budget)
     const int64_t per = (int64_t)TQ * 4;
     dim3 grid((unsigned)((n + per - 1) / per), (unsigned)c->knn_K);
     Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);

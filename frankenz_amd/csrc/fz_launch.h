@@ -122,17 +122,22 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
     if (!c->force_twopass) {
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
-        int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
-        // measured best geometry per kernel body (profiles/README.md): the chi2^(3/2) weight-space
-        // body fits 128 VGPRs and likes 4 waves/SIMD; the others want the 256-VGPR budget
-        if (tw == 4 && SRC::WPOW == 3 && src.lp.dim_prior && !getenv("FZ_NO_WSPACE")) { tw = 2; nw = 16; }
-        if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
         int r;
-        if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        else if (tw == 2 && nw == 16) r = fz_launch_fused_tw<SRC, 2, 16>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        else if (tw == 1 && nw == 4) r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        else return fail(-1, "FZ_FUSED_CFG=%d,%d is not an instantiated configuration", tw, nw);
+        if constexpr (SRC::TILE < 256) {
+            // wide records (17-32 bands): one object per wave keeps the kernel inside the register file
+            r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        } else {
+            int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
+            // measured best geometry per kernel body (profiles/README.md): the chi2^(3/2) weight-space
+            // body fits 128 VGPRs and likes 4 waves/SIMD; the others want the 256-VGPR budget
+            if (tw == 4 && SRC::WPOW == 3 && src.lp.dim_prior && !getenv("FZ_NO_WSPACE")) { tw = 2; nw = 16; }
+            if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
+            if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else if (tw == 2 && nw == 16) r = fz_launch_fused_tw<SRC, 2, 16>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else if (tw == 1 && nw == 4) r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else return fail(-1, "FZ_FUSED_CFG=%d,%d is not an instantiated configuration", tw, nw);
+        }
         if (r <= 0) return r;
     }
     FZCHK(fz_launch_stats(c, src, n, M, 0, lmap, levid));

@@ -158,3 +158,28 @@ def test_knn_other_norms_match_scipy(p):
         ids = fo.first_unique(want[i])
         np.testing.assert_array_equal(nn.neighbors[i, :len(ids)], ids)
         assert nn.Nneighbors[i] == len(ids)
+
+
+@pytest.mark.gpu
+def test_knn_wide_band_set():
+    """24 bands -> the 32-band instantiation of the query / subset kernels."""
+    from frankenz_amd import NearestNeighbors
+    d, od = dicts()
+    rs = np.random.RandomState(78)
+    M, N, B = 1500, 30, 24
+    sig = rs.uniform(0.2, 1.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .5, size=(M, B)) * 10; Ye = 0.03 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + sig * rs.randn(N, B); Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.04)
+    nn = NearestNeighbors(Y, Ye, Ym, K=4, feature_map='identity', rstate=np.random.RandomState(5), verbose=False)
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=8,
+                                 label_dict=d, return_gof=True, verbose=False)
+    feats = fo.knn_train(Y, Ye, 4, 'identity', np.random.RandomState(5))
+    q = fo.knn_query_features(X, Xe, 'identity', np.random.RandomState(6))
+    tab = fo.knn_neighbors_exact(feats, q, 8)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze,
+                                                     label_dict=od)
+    np.testing.assert_array_equal(nn.neighbors, rn)
+    np.testing.assert_allclose(nn.fit_lnprob, rlnp, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(p, rp, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(le, rle, rtol=1e-10)

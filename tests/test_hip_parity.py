@@ -202,7 +202,7 @@ def test_g7_config1_reference_mock():
     close(bf.fit_lnprob[:4], g['train_lnprob_rows'], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize('B', [3, 5, 8, 12])
+@pytest.mark.parametrize('B', [3, 5, 8, 12, 20, 32])
 @pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True},
                                 {'ignore_model_err': True, 'dim_prior': False}])
 def test_oracle_parity_band_counts(B, kw):
@@ -333,3 +333,39 @@ def test_cdf_threshold_rule_through_the_classes(kw):
     rp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze, label_dict=od, kde_kwargs=kk, **kw)[0]
     close(p, rp, **tol)
     close(nn.predict(z, ze, label_dict=d, kde_kwargs=kk, verbose=False), rp, **tol)
+
+
+@pytest.mark.parametrize('B', [17, 32])
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True},
+                                {'free_scale': True}, {'dim_prior': False}])
+def test_wide_band_sets_unmasked(B, kw):
+    """17-32 bands (the reference's COSMOS filter list holds 32) run the 32-band
+    instantiation: fused fit_predict, the planes of fit() and the mode C loop, unmasked."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(400 + B)
+    M, N = 900, 21
+    sig = rs.uniform(0.3, 2.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .5, size=(M, B)); Ye = 0.04 * Y
+    Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .3, N)[:, None] + sig * rs.randn(N, B)
+    Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = rs.uniform(0.01, 0.2, M)
+    bf = BruteForce(Y, Ye, Ym)
+    p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
+                                 lprob_kwargs=kw, return_gof=True, verbose=False, save_fits=False)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
+                                             label_dict=od, **kw)
+    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
+    rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
+    close(bf.fit_lnprob, rf['lnlike'], rtol=1e-8, atol=1e-8)
+    close(bf.fit_chi2, rf['chi2'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_array_equal(bf.fit_Ndim, rf['Ndim'])
+
+
+def test_more_than_32_bands_is_refused():
+    from frankenz_amd import BruteForce
+    Y = np.ones((10, 33))
+    with pytest.raises(Exception, match='bands unsupported'):
+        BruteForce(Y, 0.1 * Y, np.ones_like(Y)).fit(Y[:2].copy(), Y[:2].copy(), np.ones((2, 33)), verbose=False)
