@@ -21,6 +21,10 @@ class KdeOpts(C.Structure):
                 ("normalize", C.c_int32), ("cdf_thresh", C.c_double)]
 
 
+class Prior(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("P", C.c_int64), ("rows", C.c_void_p)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_planes", C.c_double), ("n_planes", C.c_int64),
                 ("ms_fused", C.c_double), ("n_fused", C.c_int64),
@@ -52,6 +56,9 @@ ABI = {
     "fz_fit": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts), _P, _P, _P, _P, _P]),
     "fz_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts),
                                  C.POINTER(KdeOpts), _P, _P, _P]),
+    "fz_fit_prior": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts), C.POINTER(Prior)] + [_P] * 7),
+    "fz_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(LikeOpts),
+                                       C.POINTER(KdeOpts), C.POINTER(Prior), _P, _P, _P]),
     "fz_predict_logwt": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_knn_upload_trees": (C.c_int, [_P, _P, _I32, _I64, _I32]),
     "fz_knn_query": (C.c_int, [_P, _P, _I64, _I32, _F64, _F64, _P]),
@@ -59,6 +66,8 @@ ABI = {
     "fz_knn_predict_logwt": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(KdeOpts), _P, _P, _P]),
     "fz_knn_fit_predict": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
                                      C.POINTER(KdeOpts)] + [_P] * 10),
+    "fz_knn_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
+                                           C.POINTER(KdeOpts), C.POINTER(Prior)] + [_P] * 12),
 }
 
 _lib = None

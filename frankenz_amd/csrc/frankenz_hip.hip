@@ -431,34 +431,127 @@ static int modec_final(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o,
 }
 
 // ---------------------------------------------------------------------------
+// additive ln-prior (fz_prior): the lnprior a user lprob_func returns per object
+// (bruteforce.py:193-199), as rows of a (P,M) table
+// ---------------------------------------------------------------------------
+__global__ void k_prior_check(const int64_t* rows, int64_t n, int64_t P, int* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (rows[i] < 0 || rows[i] >= P)) atomicExch(flag, 1);
+}
+// planes: lnprior[i][s] = tab[row(i)][col], lnprob = lnl + lnprior, col = s or nbr[i][s]
+// (k-NN subsets, padded entries s >= nnb[i] get -inf like knn.py:815-817).  lnprob may alias lnl.
+__global__ void k_prior_add(PriorView pv, const double* lnl, int64_t n, int64_t L, const int64_t* nbr, const int64_t* nnb,
+                            double* lnprior, double* lnprob) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n * L) return;
+    const int64_t i = k / L, s = k - i * L;
+    double p = 0.0;
+    if (nbr) {
+        if (s < nnb[i]) { if (pv.tab) p = pv.tab[pv.row(i) * pv.ld + nbr[k]]; }
+        else p = -INFINITY;
+    } else if (pv.tab) p = pv.tab[pv.row(i) * pv.ld + s];
+    if (lnprior) lnprior[k] = p;
+    if (lnprob) lnprob[k] = lnl[k] + p;
+}
+
+struct PriorBind {
+    const fz_prior* pr = nullptr;
+    int kind = 0;              // 0 none, 1 one row for all, 2 row i for object i, 3 rows[i]
+    bool tab_dev = false, rows_dev = false;
+    const double* tab = nullptr;           // device table when it is resident for the whole call
+    int64_t chunk_bytes_per_obj = 0;       // staging a chunk needs per object (kind 2 from host memory)
+};
+struct PriorGuard { fz_ctx* c; ~PriorGuard() { c->prior = PriorView{}; } };
+
+static int prior_begin(fz_ctx* c, const fz_prior* pr, int64_t N, int64_t M, PriorBind& pb) {
+    c->prior = PriorView{};
+    if (!pr || !pr->table) return 0;
+    if (pr->P <= 0 || pr->P >= ((int64_t)1 << 31)) return fail(-4, "ln-prior table: P = %lld rows is out of range", (long long)pr->P);
+    pb.pr = pr; pb.tab_dev = is_device_ptr(pr->table); pb.rows_dev = is_device_ptr(pr->rows);
+    if (pr->rows) pb.kind = 3;
+    else if (pr->P == 1) pb.kind = 1;
+    else if (pr->P == N) pb.kind = 2;
+    else return fail(-4, "ln-prior table has %lld rows for %lld objects and no row index", (long long)pr->P, (long long)N);
+    if (pb.tab_dev) { pb.tab = pr->table; return 0; }
+    if (pb.kind == 2) { pb.chunk_bytes_per_obj = M * 8; return 0; }
+    const size_t bytes = (size_t)pr->P * M * 8;
+    if ((int64_t)bytes > c->ws_limit) return fail(-2, "ln-prior table of %zu bytes exceeds the workspace limit", bytes);
+    FZCHK(c->d_ptab.ensure(bytes));
+    FZCHK(copy_in(c, c->d_ptab.p, pr->table, bytes));
+    pb.tab = c->d_ptab.as<double>();
+    return 0;
+}
+// point c->prior at objects [i0, i0+n)
+static int prior_chunk(fz_ctx* c, const PriorBind& pb, int64_t i0, int64_t n, int64_t M) {
+    if (!pb.kind) return 0;
+    PriorView v{}; v.ld = M;
+    if (pb.kind == 1) { v.tab = pb.tab; v.ident = 0; }
+    else if (pb.kind == 2) {
+        v.ident = 1;
+        if (pb.tab_dev) v.tab = pb.tab + i0 * M;
+        else { FZCHK(c->d_ptab.ensure((size_t)n * M * 8)); FZCHK(copy_in(c, c->d_ptab.p, pb.pr->table + i0 * M, (size_t)n * M * 8)); v.tab = c->d_ptab.as<double>(); }
+    } else {
+        v.tab = pb.tab;
+        if (pb.rows_dev) v.rows = pb.pr->rows + i0;
+        else { FZCHK(c->d_prows.ensure((size_t)n * 8)); FZCHK(copy_in(c, c->d_prows.p, pb.pr->rows + i0, (size_t)n * 8)); v.rows = c->d_prows.as<int64_t>(); }
+        FZCHK(c->d_flags.ensure(64));
+        HIPCHK(hipMemsetAsync(c->d_flags.p, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_prior_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, v.rows, n, pb.pr->P, c->d_flags.as<int>());
+        HIPCHK(hipGetLastError());
+        int ef = 0;
+        FZCHK(copy_out(c, &ef, c->d_flags.p, sizeof ef));
+        if (ef) return fail(-3, "ln-prior row index outside [0, %lld)", (long long)pb.pr->P);
+    }
+    c->prior = v;
+    return 0;
+}
+static int prior_add(fz_ctx* c, const double* lnl, int64_t n, int64_t L, const int64_t* nbr, const int64_t* nnb, double* lnprior,
+                     double* lnprob) {
+    if (!lnprior && !lnprob) return 0;
+    const int64_t tot = n * L;
+    Timer t(c, &c->tm.ms_other, &c->tm.n_other);
+    hipLaunchKernelGGL(k_prior_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->prior, lnl, n, L, nbr, nnb,
+                       lnprior, lnprob);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // fz_fit : BruteForce._fit (bruteforce.py:127-205)
 // ---------------------------------------------------------------------------
-extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o, double* lnlike,
-                      double* chi2, int64_t* ndim, double* scale, double* scale_err) {
+extern "C" int fz_fit_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o, const fz_prior* pr,
+                            double* lnprior, double* lnlike, double* lnprob, double* chi2, int64_t* ndim, double* scale,
+                            double* scale_err) {
     if (!c || !x || !xe || !xm || !o) return fail(-1, "fz_fit: NULL argument");
     if (!c->M) return fail(-1, "fz_fit: models have not been uploaded");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
     const int mode = like_mode(o);
     const int64_t M = c->M;
-    void* outs[5] = {lnlike, chi2, ndim, scale, scale_err};
-    bool dev_out[5]; int nstage = 0;
-    for (int k = 0; k < 5; ++k) { dev_out[k] = is_device_ptr(outs[k]); if (outs[k] && !dev_out[k]) ++nstage; }
-    // chunk so that staging planes (+ mode C state) fit the workspace budget
+    PriorBind pb; PriorGuard guard{c};
+    FZCHK(prior_begin(c, pr, N, M, pb));
+    constexpr int NO = 7;
+    void* outs[NO] = {lnlike, chi2, ndim, scale, scale_err, lnprior, lnprob};
+    const bool need_lnl = lnlike || lnprob;
+    bool dev_out[NO]; int nstage = 0;
+    for (int k = 0; k < NO; ++k) { dev_out[k] = is_device_ptr(outs[k]); if (outs[k] && !dev_out[k]) ++nstage; }
+    if (!lnlike && lnprob) ++nstage;               // scratch ln-like plane behind lnprob
+    // chunk so that staging planes (+ mode C state, + a host prior's rows) fit the workspace budget
     const int64_t row = M * 8;
-    int64_t nplanes = nstage + (mode == 3 ? 4 : 0);
-    int64_t nc = nplanes ? std::max<int64_t>(1, c->ws_limit / (row * nplanes)) : N;
+    const int64_t per_obj = row * (nstage + (mode == 3 ? 4 : 0)) + pb.chunk_bytes_per_obj;
+    int64_t nc = per_obj ? std::max<int64_t>(1, c->ws_limit / per_obj) : N;
     nc = std::min<int64_t>(std::min<int64_t>(nc, N), 1 << 18);
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
         FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
+        FZCHK(prior_chunk(c, pb, i0, n, M));
         const int var = pick_var(c, fl);
         const bool masked = var != VAR_FAST;
-        void* dst[5];
-        for (int k = 0; k < 5; ++k) {
-            if (!outs[k]) dst[k] = nullptr;
-            else if (dev_out[k]) dst[k] = (char*)outs[k] + (size_t)i0 * row;
+        void* dst[NO];
+        for (int k = 0; k < NO; ++k) {
+            if (!outs[k] && !(k == 0 && need_lnl)) dst[k] = nullptr;
+            else if (outs[k] && dev_out[k]) dst[k] = (char*)outs[k] + (size_t)i0 * row;
             else { FZCHK(c->d_pl[k].ensure((size_t)n * row)); dst[k] = c->d_pl[k].p; }
         }
         if (mode == 3) {
@@ -468,11 +561,16 @@ extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, c
             FZCHK(run_planes(c, mode, var, o->dim_prior, n, (double*)dst[0], (double*)dst[1], (int64_t*)dst[2], (double*)dst[3],
                              (double*)dst[4]));
         }
-        for (int k = 0; k < 5; ++k)
+        FZCHK(prior_add(c, (const double*)dst[0], n, M, nullptr, nullptr, (double*)dst[5], (double*)dst[6]));
+        for (int k = 0; k < NO; ++k)
             if (outs[k] && !dev_out[k]) FZCHK(copy_out(c, (char*)outs[k] + (size_t)i0 * row, dst[k], (size_t)n * row));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o, double* lnlike,
+                      double* chi2, int64_t* ndim, double* scale, double* scale_err) {
+    return fz_fit_prior(c, x, xe, xm, N, o, nullptr, nullptr, lnlike, nullptr, chi2, ndim, scale, scale_err);
 }
 
 // ---------------------------------------------------------------------------
@@ -480,6 +578,10 @@ extern "C" int fz_fit(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, c
 // ---------------------------------------------------------------------------
 extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o,
                               const fz_kde_opts* ko, double* pdfs, double* lmap, double* levid) {
+    return fz_fit_predict_prior(c, x, xe, xm, N, o, ko, nullptr, pdfs, lmap, levid);
+}
+extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o,
+                                    const fz_kde_opts* ko, const fz_prior* pr, double* pdfs, double* lmap, double* levid) {
     if (!c || !x || !xe || !xm || !o || !pdfs) return fail(-1, "fz_fit_predict: NULL argument");
     if (!c->M) return fail(-1, "fz_fit_predict: models have not been uploaded");
     FZCHK(check_kde_opts(ko));
@@ -490,13 +592,16 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
     const bool pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
     const bool cdf = !ko->use_wt_thresh;          // reference CDF rule: materialise the chunk's ln-like rows
+    PriorBind pb; PriorGuard guard{c};
+    FZCHK(prior_begin(c, pr, N, M, pb));
     int64_t nc = std::min<int64_t>(N, 1 << 18);
-    if (mode == 3) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / (M * 8 * 4)));
-    else if (cdf) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / (M * 8)));
+    const int64_t per_obj = M * 8 * (mode == 3 ? 4 : (cdf ? 1 : 0)) + pb.chunk_bytes_per_obj;
+    if (per_obj) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / per_obj));
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
         FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
+        FZCHK(prior_chunk(c, pb, i0, n, M));
         const int var = pick_var(c, fl);
         const bool masked = var != VAR_FAST;
         double* d_pdf; double* d_lm; double* d_le;
@@ -507,6 +612,7 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
             FZCHK(run_modec(c, var, n, o));
             double* lpl = c->d_mc[1].as<double>();
             FZCHK(modec_final(c, n, masked, o, lpl, nullptr, nullptr, nullptr, nullptr));   // in place: lnl plane
+            if (c->prior.tab) FZCHK(prior_add(c, lpl, n, M, nullptr, nullptr, nullptr, lpl));
             if (cdf) {
                 FZCHK(run_cdf(c, n, (int)M, M, lpl, nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
             } else {
@@ -517,6 +623,7 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
         } else if (cdf) {
             FZCHK(c->d_pl[0].ensure((size_t)n * M * 8));
             FZCHK(run_planes(c, mode, var, o->dim_prior, n, c->d_pl[0].as<double>(), nullptr, nullptr, nullptr, nullptr));
+            if (c->prior.tab) FZCHK(prior_add(c, c->d_pl[0].as<double>(), n, M, nullptr, nullptr, nullptr, c->d_pl[0].as<double>()));
             FZCHK(run_cdf(c, n, (int)M, M, c->d_pl[0].as<double>(), nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
         } else {
             FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));

@@ -41,6 +41,16 @@ struct ObjView {
     const uint32_t* bits;  // data_mask bits
     const double* slv;     // sum over the B real bands of log(xe^2) (UNMASKED, pdf.py:96-98)
 };
+// Additive ln-prior (extension; SURVEY 8f-1 -- the lnprior a custom lprob_func returns,
+// bruteforce.py:193-194): row-major table of ln-prior rows over the M models and the row
+// each object of the chunk reads.  lnprob[i][j] = lnlike[i][j] + tab[row(i) * ld + j].
+struct PriorView {
+    const double* tab;     // nullptr: no prior
+    const int64_t* rows;   // [n] row per object (validated against P on the device), or nullptr
+    int64_t ident;         // rows == nullptr: 1 -> object i reads row i, 0 -> every object reads row 0
+    int64_t ld;            // row length (= M)
+    __device__ __forceinline__ int64_t row(int64_t i) const { return rows ? rows[i] : (ident ? i : 0); }
+};
 struct LikeParams {
     int dim_prior;
     const double* lgtab;   // [BT+1] gammaln(a)+a*ln2, a=n/2 (modes 0,1) or (n-1)/2 (mode 2)

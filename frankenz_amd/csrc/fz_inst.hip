@@ -61,6 +61,11 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
                               double* levid, double* pdfs) {
     const int64_t M = c->M;
 #define FZ_CALL_FUSED(BT_, MODE_, VAR_)                                                                   \
+    if (c->prior.tab) {                                                                                    \
+        PhotSrc<BT_, MODE_, VAR_, true> ph; ph.mv = model_view(c); ph.ov = obj_view(c);                    \
+        ph.lp = like_params(c, MODE_, dim_prior); ph.pv = c->prior;                                        \
+        return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);                                   \
+    }                                                                                                      \
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
     FZ_SWITCH(FZ_CALL_FUSED)

@@ -35,27 +35,48 @@ struct PlaneSrc {
         return valid ? o.row[j] : -INFINITY;
     }
 };
-template <int BT, int MODE, int VAR>
+template <int BT, int MODE, int VAR, bool PRI = false>
 struct PhotSrc : Phot<BT, MODE, VAR> {
     using P = Phot<BT, MODE, VAR>;
     // With the dimensionality prior and no masks the likelihood is chi2^(WPOW/2) e^(-chi2/2)/C
     // with a compile-time half-integer power (B = 5: 3/2 for modes A/Ai, 1 for mode B), so
     // the weight can be formed with a square root instead of a logarithm (k_fused, WM).
-    static constexpr int WPOW = (VAR == VAR_FAST) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
+    // An additive ln-prior (PRI) keeps to the ln-space body, which tracks nan / +-inf rows.
+    static constexpr int WPOW = (VAR == VAR_FAST && !PRI) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
+    static constexpr bool HAS_PRIOR = PRI;
+    PriorView pv;                                 // read only when PRI
+    struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
+    __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {
+        P::load_obj(i, o);
+        if (PRI) o.prow = pv.tab + pv.row(i) * pv.ld;
+    }
+    // the row index (< 2^31, checked on the host) rides in the spare high word of the
+    // parked object row's mask slot
+    __device__ __forceinline__ void park_obj(int64_t i, double* dst, int lane) const {
+        P::park_obj(i, dst, lane);
+        if (PRI && lane == BT) dst[2 * BT + 1] = __hiloint2double((int)pv.row(i), P::MASKED ? (int)P::ov.bits[i] : -1);
+    }
+    __device__ __forceinline__ void load_obj_lds(const double* p, OR& o) const {
+        P::load_obj_lds(p, o);
+        if (PRI) o.prow = pv.tab + (int64_t)__double2hiint(p[2 * BT + 1]) * pv.ld;
+    }
     __device__ __forceinline__ double chi2_of(const typename P::OR& o, const typename P::MR& m) const {
         return P::template eval<1>(o, m).chi2;          // the unused ln-like tail is dead code
     }
     __device__ __forceinline__ double lnl_of_chi2(double chi2) const {
         return chi2_logpdf<true>(0.5 * WPOW, chi2, P::lp.lg_full, P::tb);
     }
-    __device__ __forceinline__ double lnl(const typename P::OR& o, const typename P::MR& m,
-                                          int64_t, bool valid) const {
-        const double l = P::eval(o, m).lnl;       // pad lanes hold benign data; no divergent branch
+    __device__ __forceinline__ double lnl(const OR& o, const typename P::MR& m, int64_t j, bool valid) const {
+        double l = P::eval(o, m).lnl;             // pad lanes hold benign data; no divergent branch
+        if (PRI) l += valid ? o.prow[j] : 0.0;
         return valid ? l : -INFINITY;
     }
+    // j / inb: the lane's model and whether it is a real one (only the prior read needs them)
     template <int DPT>
-    __device__ __forceinline__ double lnl_t(const typename P::OR& o, const typename P::MR& m) const {
-        return P::template eval<DPT>(o, m).lnl;
+    __device__ __forceinline__ double lnl_t(const OR& o, const typename P::MR& m, int j, bool inb) const {
+        double l = P::template eval<DPT>(o, m).lnl;
+        if (PRI) l += inb ? o.prow[j] : 0.0;
+        return l;
     }
 
     // ---- LDS-staged model tiles (k_fused) ----
@@ -365,7 +386,7 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
         for (int o = 0; o < TW; ++o) {
             typename SRC::OR ob;
             src.load_obj_lds(objs + o * OD, ob);
-            l[o] = src.template lnl_t<DPT>(ob, m);
+            l[o] = src.template lnl_t<DPT>(ob, m, j, TAIL ? (j < M) : true);
             if (TAIL) l[o] = (j < M) ? l[o] : -INFINITY;
         }
 #pragma unroll

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import KdeOpts, LikeOpts, Timing, check, ptr
+from ._lib import KdeOpts, LikeOpts, Prior, Timing, check, ptr
 
 _LIKE_KEYS = ("free_scale", "ignore_model_err", "dim_prior", "ltol", "return_scale")
 
@@ -126,6 +126,28 @@ class Engine(object):
         check(self.lib.fz_fit_predict(self.h, ptr(x), ptr(xe), ptr(xm), n, C.byref(opts),
                                       C.byref(kopts), ptr(pdfs), ptr(lmap), ptr(levid)))
 
+    @staticmethod
+    def _prior_struct(prior):
+        """(table, P, rows) -> fz_prior*, or NULL.  The arrays must outlive the call."""
+        if prior is None:
+            return None
+        table, P, rows = prior
+        return C.byref(Prior(ptr(table), int(P), ptr(rows)))
+
+    def fit_prior(self, x, xe, xm, opts, prior, lnprior=None, lnlike=None, lnprob=None, chi2=None,
+                  ndim=None, scale=None, scale_err=None, n=None):
+        """fz_fit_prior: ``prior`` is ``(table (P,M), P, rows (n,) or None)`` or None."""
+        n = len(x) if n is None else n
+        check(self.lib.fz_fit_prior(self.h, ptr(x), ptr(xe), ptr(xm), n, C.byref(opts),
+                                    self._prior_struct(prior), ptr(lnprior), ptr(lnlike), ptr(lnprob),
+                                    ptr(chi2), ptr(ndim), ptr(scale), ptr(scale_err)))
+
+    def fit_predict_prior(self, x, xe, xm, opts, kopts, prior, pdfs, lmap=None, levid=None, n=None):
+        n = len(x) if n is None else n
+        check(self.lib.fz_fit_predict_prior(self.h, ptr(x), ptr(xe), ptr(xm), n, C.byref(opts),
+                                            C.byref(kopts), self._prior_struct(prior), ptr(pdfs),
+                                            ptr(lmap), ptr(levid)))
+
     def predict_logwt(self, logwt, kopts, pdfs, lmap=None, levid=None, is_log=True, n=None):
         n = len(logwt) if n is None else n
         check(self.lib.fz_predict_logwt(self.h, ptr(logwt), n, int(bool(is_log)), C.byref(kopts),
@@ -149,6 +171,16 @@ class Engine(object):
                                           C.byref(opts), C.byref(kopts) if kopts is not None else None,
                                           ptr(neighbors), ptr(nnbr), ptr(lnlike), ptr(chi2), ptr(ndim),
                                           ptr(scale), ptr(scale_err), ptr(pdfs), ptr(lmap), ptr(levid)))
+
+    def knn_fit_predict_prior(self, x, xe, xm, idx, W, opts, kopts, prior, neighbors=None, nnbr=None,
+                              lnprior=None, lnlike=None, lnprob=None, chi2=None, ndim=None, scale=None,
+                              scale_err=None, pdfs=None, lmap=None, levid=None, n=None):
+        n = len(x) if n is None else n
+        check(self.lib.fz_knn_fit_predict_prior(
+            self.h, ptr(x), ptr(xe), ptr(xm), n, ptr(idx), int(W), C.byref(opts),
+            C.byref(kopts) if kopts is not None else None, self._prior_struct(prior), ptr(neighbors),
+            ptr(nnbr), ptr(lnprior), ptr(lnlike), ptr(lnprob), ptr(chi2), ptr(ndim), ptr(scale),
+            ptr(scale_err), ptr(pdfs), ptr(lmap), ptr(levid)))
 
     def knn_predict_logwt(self, logwt, neighbors, nnbr, W, kopts, pdfs, lmap=None, levid=None, n=None):
         n = len(logwt) if n is None else n

@@ -145,11 +145,26 @@ class NearestNeighbors():
         self.fit_scale = np.ones((Ndata, W), dtype='float')
         self.fit_scale_err = np.zeros((Ndata, W), dtype='float')
 
-    def _run(self, eng, obj, q, lo, hi, opts, ko, track_scale, save_fits, pdfs=None, lmap=None, levid=None):
+    def _run(self, eng, obj, q, lo, hi, opts, ko, track_scale, save_fits, pdfs=None, lmap=None, levid=None,
+             prior=None):
         """search + subset likelihood (+ PDFs) for objects [lo,hi)."""
         n, W = hi - lo, self.K * self.k
         idx = np.empty((n, W), dtype=np.int64)
         eng.knn_query(q[lo:hi], self.k, self.dbound, idx, n=n, lp_norm=self.lp_norm)
+        if prior is not None:
+            # additive ln-prior (pdf.logprob_prior): the three probability planes come from the device
+            kw = {}
+            if save_fits:
+                sl = slice(lo, hi)
+                free = bool(opts.free_scale)
+                kw = dict(neighbors=self.neighbors[sl], nnbr=self.Nneighbors[sl], lnprior=self.fit_lnprior[sl],
+                          lnlike=self.fit_lnlike[sl], lnprob=self.fit_lnprob[sl], chi2=self.fit_chi2[sl],
+                          ndim=self.fit_Ndim[sl],
+                          scale=self.fit_scale[sl] if (track_scale and free) else None,
+                          scale_err=self.fit_scale_err[sl] if (track_scale and free) else None)
+            eng.knn_fit_predict_prior(obj.x[lo:hi], obj.xe[lo:hi], obj.xm[lo:hi], idx, W, opts, ko,
+                                      prior.chunk(lo, hi, len(obj.x)), pdfs=pdfs, lmap=lmap, levid=levid, n=n, **kw)
+            return idx
         kw = {}
         if save_fits:
             sl = slice(lo, hi)
@@ -171,7 +186,7 @@ class NearestNeighbors():
     def fit(self, data, data_err, data_mask, lprob_func=None, rstate=None, k=20, eps=1e-3, lp_norm=2,
             distance_upper_bound=np.inf, lprob_args=None, lprob_kwargs=None, track_scale=False, verbose=True):
         """knn.py:190-279."""
-        _check_lprob(lprob_func, lprob_args)
+        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
         opts = like_opts(lprob_kwargs)
         if rstate is None:
             rstate = np.random
@@ -182,7 +197,7 @@ class NearestNeighbors():
         Ndata = len(obj.x)
         self.NDATA = Ndata
         self._alloc_fits(Ndata)
-        self._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True)
+        self._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True, prior=prior)
         obj.writeback()
         _progress(verbose, 'Fitting object', Ndata, Ndata)
         if verbose:
@@ -193,7 +208,7 @@ class NearestNeighbors():
              track_scale=False, save_fits=True):
         """Generator twin (knn.py:281-388): yields ``(idxs, Nidx, results)`` per object;
         uses the ``k / eps / lp_norm / dbound`` attributes like the reference."""
-        _check_lprob(lprob_func, lprob_args)
+        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
         opts = like_opts(lprob_kwargs)
         if rstate is None:
             rstate = np.random
@@ -205,7 +220,7 @@ class NearestNeighbors():
         self.NDATA = Ndata
         keep = self if save_fits else copy.copy(self)      # scratch holder when fits are not kept
         keep._alloc_fits(Ndata)
-        keep._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True)
+        keep._run(eng, obj, q, 0, Ndata, opts, None, track_scale, True, prior=prior)
         obj.writeback()
         for i in range(Ndata):
             n = keep.Nneighbors[i]
@@ -261,7 +276,7 @@ class NearestNeighbors():
                     label_grid=None, kde_args=None, kde_kwargs=None, lprob_args=None, lprob_kwargs=None,
                     return_gof=False, track_scale=False, verbose=True, save_fits=True):
         """knn.py:560-720."""
-        _check_lprob(lprob_func, lprob_args)
+        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
         if kde_args:
             raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
         if label_dict is None and label_grid is None:
@@ -281,7 +296,7 @@ class NearestNeighbors():
         if save_fits:
             self.NDATA = Ndata
             self._alloc_fits(Ndata)
-        self._run(eng, obj, q, 0, Ndata, opts, ko, track_scale, save_fits, pdfs, lmap, levid)
+        self._run(eng, obj, q, 0, Ndata, opts, ko, track_scale, save_fits, pdfs, lmap, levid, prior=prior)
         obj.writeback()
         _progress(verbose, 'Generating PDF', Ndata, Ndata)
         if verbose:

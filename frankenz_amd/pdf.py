@@ -16,8 +16,8 @@ import numpy as np
 
 from .engine import HostObjects, get_engine, kde_opts, like_opts
 
-__all__ = ["loglike", "logprob", "gaussian", "gauss_kde", "gauss_kde_dict", "magnitude",
-           "luptitude", "PDFDict"]
+__all__ = ["loglike", "logprob", "logprob_prior", "gaussian", "gauss_kde", "gauss_kde_dict",
+           "magnitude", "luptitude", "PDFDict"]
 
 
 def _ndim_dtype(data_mask, models_mask):
@@ -64,6 +64,73 @@ def logprob(data, data_err, data_mask, models, models_err, models_mask, free_sca
                   ltol=ltol, return_scale=return_scale, *args, **kwargs)
     lnl = res[0]
     return (np.zeros_like(lnl), lnl, lnl[:]) + tuple(res[1:])
+
+
+class logprob_prior(object):
+    """``lprob_func`` with an additive ln-prior, passed as DATA so that it can run on
+    the device (extension; the reference's hook is a Python callable returning
+    ``(lnprior, lnlike, lnlike + lnprior, ...)`` per object -- bruteforce.py:193-199,
+    demos/2 cell 69's ``lprob_bpz``).
+
+    ``lnprior`` is a ``(P, Nmodel)`` float64 table of ln-prior rows (NumPy array or a
+    device tensor exposing ``data_ptr()``; ``(Nmodel,)`` means one shared row) and
+    ``rows`` the ``(Ndata,)`` row each object reads.  Without ``rows``: ``P == 1``
+    broadcasts, ``P == Ndata`` is a dense per-object prior.  ``lprob_kwargs`` keep
+    their meaning (free_scale, ignore_model_err, dim_prior, ltol).
+
+    Pass an instance as ``lprob_func=`` to ``BruteForce`` / ``NearestNeighbors``.
+    Calling it for one object with the reference's signature also works
+    (``row=`` picks the table row)."""
+
+    def __init__(self, lnprior, rows=None):
+        if isinstance(lnprior, np.ndarray) or not hasattr(lnprior, "data_ptr"):
+            lnprior = np.atleast_2d(np.ascontiguousarray(lnprior, dtype=np.float64))
+        elif lnprior.dim() != 2 or not lnprior.is_contiguous() or lnprior.element_size() != 8:
+            raise ValueError("a device ln-prior table must be a contiguous 2-D float64 tensor")
+        self.table = lnprior
+        self.P, self.M = int(lnprior.shape[0]), int(lnprior.shape[1])
+        if rows is not None and (isinstance(rows, np.ndarray) or not hasattr(rows, "data_ptr")):
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+        self.rows = rows
+
+    def chunk(self, lo, hi, Ndata):
+        """the ``(table, P, rows)`` triple of objects [lo, hi) out of Ndata"""
+        if self.rows is not None:
+            if len(self.rows) != Ndata:
+                raise ValueError("ln-prior `rows` has %d entries for %d objects" % (len(self.rows), Ndata))
+            return self.table, self.P, self.rows[lo:hi]
+        if self.P == 1:
+            return self.table, 1, None
+        if self.P != Ndata:
+            raise ValueError("ln-prior table has %d rows for %d objects and no `rows`" % (self.P, Ndata))
+        return self.table[lo:hi], hi - lo, None
+
+    def __call__(self, data, data_err, data_mask, models, models_err, models_mask, row=0,
+                 free_scale=False, ignore_model_err=False, dim_prior=True, ltol=1e-4,
+                 return_scale=False, device=None):
+        eng = get_engine(device)
+        eng.upload_models(models, models_err, models_mask)
+        if eng.M != self.M:
+            raise ValueError("ln-prior rows hold %d models, the model set %d" % (self.M, eng.M))
+        obj = HostObjects(np.atleast_2d(data), np.atleast_2d(data_err), np.atleast_2d(data_mask))
+        M = eng.M
+        lnp, lnl, lpr, chi2 = (np.empty((1, M)) for _ in range(4))
+        ndim = np.empty((1, M), dtype=np.int64)
+        sc = se = None
+        if free_scale and return_scale:
+            sc, se = np.empty((1, M)), np.empty((1, M))
+        opts = like_opts(dict(free_scale=free_scale, ignore_model_err=ignore_model_err,
+                              dim_prior=dim_prior, ltol=ltol))
+        rows = np.array([row], dtype=np.int64)
+        eng.fit_prior(obj.x, obj.xe, obj.xm, opts, (self.table, self.P, rows), lnp, lnl, lpr, chi2,
+                      ndim, sc, se)
+        for dst, buf in ((data, obj.x), (data_err, obj.xe), (data_mask, obj.xm)):
+            if isinstance(dst, np.ndarray) and not np.shares_memory(dst, buf):
+                dst[...] = buf.reshape(dst.shape)
+        out = (lnp[0], lnl[0], lpr[0], ndim[0].astype(_ndim_dtype(data_mask, models_mask)), chi2[0])
+        if free_scale and return_scale:
+            out = out + (sc[0], se[0])
+        return out
 
 
 def gaussian(mu, std, x):

@@ -111,6 +111,32 @@ int  fz_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
                     const fz_like_opts* opts, const fz_kde_opts* kde,
                     double* pdfs, double* lmap, double* levid);
 
+/* ---- additive ln-prior (extension) ----
+ * The reference's plug-in point is lprob_func, called once per object and returning
+ * (lnprior, lnlike, lnprob = lnlike + lnprior, ...) (bruteforce.py:193-199; the BPZ
+ * posterior of demos/2 cell 69 is the one use).  A Python callable cannot run on the
+ * device, so the prior is passed as data: a (P,M) table of ln-prior rows over the M
+ * models plus the row each object reads (e.g. P magnitude bins of P(z,t|m), or P = N
+ * for a dense per-object prior, or P = 1 for one prior shared by all objects).
+ * lnprob[i][j] = lnlike[i][j] + table[rows[i]][j].  -inf entries (prior 0) and nan
+ * propagate as they do through the reference's lnlike + lnprior. */
+typedef struct fz_prior {
+    const double*  table;  /* (P,M) float64 row-major, host or device          */
+    int64_t        P;      /* 1 <= P < 2^31                                     */
+    const int64_t* rows;   /* (N) int64 in [0,P), host or device; NULL means
+                              row 0 for everybody if P == 1, row i if P == N    */
+} fz_prior;
+/* fz_fit with the three probability planes of bruteforce.py:197-199 (prior may be
+ * NULL: lnprior = 0, lnprob = lnlike, pdf.py:404-405). */
+int  fz_fit_prior(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+                  const fz_like_opts* opts, const fz_prior* prior, double* lnprior,
+                  double* lnlike, double* lnprob, double* chi2, int64_t* ndim,
+                  double* scale, double* scale_err);
+/* fz_fit_predict weighting by lnprob = lnlike + lnprior (bruteforce.py:618-620). */
+int  fz_fit_predict_prior(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+                          const fz_like_opts* opts, const fz_kde_opts* kde,
+                          const fz_prior* prior, double* pdfs, double* lmap, double* levid);
+
 /* BruteForce._predict (bruteforce.py:303-372): rows of logwt (N,M) -> PDFs.
  * is_log=0 treats the rows as linear weights y_wt and skips the softmax
  * (gauss_kde / gauss_kde_dict called directly, pdf.py:444, 529). */
@@ -133,6 +159,16 @@ int  fz_knn_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t 
                         const fz_kde_opts* kde, int64_t* neighbors, int64_t* nnbr,
                         double* lnlike, double* chi2, int64_t* ndim, double* scale,
                         double* scale_err, double* pdfs, double* lmap, double* levid);
+
+/* the same with an additive ln-prior (see fz_prior): lnprior[i][s] = table[rows[i]][
+ * neighbors[i][s]], lnprob = lnlike + lnprior, padded with -inf like knn.py:815-817;
+ * PDFs are weighted by lnprob (knn.py:859-863).  prior may be NULL (lnprior = 0). */
+int  fz_knn_fit_predict_prior(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
+                              const int64_t* idx, int64_t W, const fz_like_opts* opts,
+                              const fz_kde_opts* kde, const fz_prior* prior, int64_t* neighbors,
+                              int64_t* nnbr, double* lnprior, double* lnlike, double* lnprob,
+                              double* chi2, int64_t* ndim, double* scale, double* scale_err,
+                              double* pdfs, double* lmap, double* levid);
 
 /* NearestNeighbors._predict (knn.py:488-558): PDFs from stored (N,W) ln-weights,
  * the stored neighbour table (N,W) and counts (N). */

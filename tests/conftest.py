@@ -26,6 +26,54 @@ def golden():
     return load_golden
 
 
+class DevArray(object):
+    """A float64 / int64 array in device memory, allocated through the SAME HIP runtime the
+    library is linked against (ctypes on libamdhip64), exposing the few tensor-like members
+    the host layer looks at.  Lets the -m gpu tests pass device pointers across the C ABI
+    without bringing up a second GPU runtime stack in the test process."""
+    _hip = None
+
+    def __init__(self, a=None, _ptr=None, _shape=None, _base=None):
+        import ctypes as C
+        if DevArray._hip is None:
+            DevArray._hip = C.CDLL('libamdhip64.so.7')
+        if a is None:
+            self._ptr, self.shape, self._base = _ptr, _shape, _base
+            return
+        a = np.ascontiguousarray(a)
+        assert a.dtype.itemsize == 8
+        p = C.c_void_p()
+        assert DevArray._hip.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 8))) == 0
+        assert DevArray._hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0
+        self._ptr, self.shape, self._base = p.value, a.shape, None
+
+    def data_ptr(self):
+        return self._ptr
+
+    def dim(self):
+        return len(self.shape)
+
+    def is_contiguous(self):
+        return True
+
+    def element_size(self):
+        return 8
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, sl):                      # contiguous row range -> view
+        lo, hi, st = sl.indices(self.shape[0])
+        assert st == 1
+        row = 8 * int(np.prod(self.shape[1:], dtype=np.int64))
+        return DevArray(_ptr=self._ptr + lo * row, _shape=(hi - lo,) + tuple(self.shape[1:]), _base=self)
+
+    def __del__(self):
+        if self._base is None and self._ptr and DevArray._hip is not None:
+            import ctypes as C
+            DevArray._hip.hipFree(C.c_void_p(self._ptr))
+
+
 def have_gpu():
     try:
         import torch

@@ -369,7 +369,91 @@ def g7():
     save('g7_config1', **out)
 
 
+def g8():
+    """The lprob_func hook with an additive prior, shaped like demos/2 cell 69's
+    ``lprob_bpz``: ln-prior row picked from a small table by the object's
+    magnitude in a reference band; returns (lnprior, lnlike, lnlike + lnprior,
+    ndim, chi2).  Pins fit_lnprior / fit_lnprob, predict() on the posterior and
+    the fused fit_predict through the REFERENCE's own BruteForce loops."""
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(808, 18, 140)
+    d = demo_dict()
+    rs = np.random.RandomState(8)
+    P, M = 6, len(Y)
+    prob = rs.dirichlet(np.full(M, 0.3), size=P)
+    prob[1, rs.choice(M, 9, replace=False)] = 0.0       # prior 0 -> lnprior -inf
+    table = np.log(prob)
+    edges = np.array([-1.5, -0.5, 0.3, 1.0, 2.0])
+    rows_seen = []
+
+    def make_hook(**likekw):
+        def lprob(x, xe, xm, ys, yes, yms):
+            res = rpdf.loglike(x, xe, xm, ys, yes, yms, **likekw)
+            lnlike, ndim, chi2 = res[:3]
+            mag = -2.5 * np.log10(max(x[1], 1e-3))          # x is already cleaned in place
+            row = int(np.searchsorted(edges, mag))
+            rows_seen.append(row)
+            lnprior = table[row]
+            return lnprior, lnlike, lnlike + lnprior, ndim, chi2
+        return lprob
+
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm, z=z, ze=ze, table=table)
+    for tag, kw in (('A', {}), ('B', {'free_scale': True, 'ignore_model_err': True})):
+        del rows_seen[:]
+        bf = BruteForce(Y, Ye, Ym)
+        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_func=make_hook(**kw), verbose=False)
+        out['rows'] = np.array(rows_seen, dtype='int')
+        out[tag + '_lnprior'], out[tag + '_lnlike'] = bf.fit_lnprior, bf.fit_lnlike
+        out[tag + '_lnprob'] = bf.fit_lnprob
+        p, (lm, le) = bf.predict(z, ze, label_dict=d, return_gof=True, verbose=False)
+        out[tag + '_pred'], out[tag + '_lmap'], out[tag + '_levid'] = p, lm, le
+        out[tag + '_pred_like'] = bf.predict(z, ze, label_dict=d, logwt=bf.fit_lnlike, verbose=False)
+        bf2 = BruteForce(Y, Ye, Ym)
+        out[tag + '_fp'] = bf2.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, lprob_func=make_hook(**kw),
+                                           label_dict=d, verbose=False, save_fits=False)
+        out[tag + '_fp_grid'] = bf2.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, lprob_func=make_hook(**kw),
+                                                label_grid=d.grid, verbose=False, save_fits=False)
+    save('g8_prior_hook', **out)
+
+
+def g9():
+    """NearestNeighbors with an lprob_func hook: the hook only sees models[idxs]
+    (knn.py:847-849), so its prior is a function of each model's own photometry
+    -- the same for every object, i.e. ONE ln-prior row over the models.  eps=0
+    (exact search) so that the neighbour table does not depend on KDTree pruning."""
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(909, 22, 300)
+    X[2, 3] = 1.0
+    Xe[5, 0] = SDSS_SIGMA[0]
+    d = demo_dict()
+
+    def lnp_of(ys):
+        return -0.5 * np.square((np.log(ys[:, 2]) - 1.0) / 0.7) - 0.3 * np.log(ys[:, 0])
+
+    def hook(x, xe, xm, ys, yes, yms, **likekw):
+        res = rpdf.loglike(x, xe, xm, ys, yes, yms, **likekw)
+        lnlike, ndim, chi2 = res[:3]
+        lnprior = lnp_of(ys)
+        return (lnprior, lnlike, lnlike + lnprior, ndim, chi2) + tuple(res[3:])
+
+    out = dict(Y=Y, Ye=Ye, Ym=Ym, X=X, Xe=Xe, Xm=Xm, z=z, ze=ze, row=lnp_of(Y))
+    for tag, kw, ts in (('A', {}, False),
+                        ('B', {'free_scale': True, 'ignore_model_err': True, 'return_scale': True}, True)):
+        nn = NearestNeighbors(Y, Ye, Ym, K=5, feature_map='identity', rstate=np.random.RandomState(1), verbose=False)
+        p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, lprob_func=hook, lprob_kwargs=kw,
+                                     rstate=np.random.RandomState(2), k=4, eps=0.0, label_dict=d, return_gof=True,
+                                     track_scale=ts, verbose=False)
+        out[tag + '_pdfs'], out[tag + '_lmap'], out[tag + '_levid'] = p, lm, le
+        out[tag + '_neighbors'], out[tag + '_Nneighbors'] = nn.neighbors, nn.Nneighbors
+        for nm in ('lnprior', 'lnlike', 'lnprob', 'chi2', 'scale'):
+            out[tag + '_' + nm] = getattr(nn, 'fit_' + nm)
+        out[tag + '_pred'] = nn.predict(z, ze, label_dict=d, verbose=False)
+    save('g9_knn_prior_hook', **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:
+        for nm in sys.argv[1:]:
+            globals()[nm]()
+        sys.exit(0)
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))

@@ -244,3 +244,38 @@ def test_g7_config1_reference_mock():
                                           np.full(len(obs), 0.03), label_dict=d)
     eq(p[:16], g['train_pdfs16'], rtol=1e-10, atol=1e-14)
     eq(lm, g['train_lmap'][:n], rtol=1e-11, atol=0); eq(le, g['train_levid'][:n], rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize('tag,kw', [('A', {}), ('B', {'free_scale': True, 'ignore_model_err': True})])
+def test_g8_prior_hook(tag, kw):
+    """the additive ln-prior against the REFERENCE's lprob_func hook (demos/2 cell 69 shape)."""
+    g = load_golden('g8_prior_hook')
+    lp = g['table'][g['rows']]
+    rf = fo.bruteforce_fit(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['Y'], g['Ye'], g['Ym'], lnprior=lp, **kw)
+    for k in ('lnprior', 'lnlike', 'lnprob'):
+        eq(rf[k], g[tag + '_' + k])
+    d = demo_dict()
+    p, lm, le = fo.bruteforce_predict(rf['lnprob'], g['z'], g['ze'], label_dict=d)
+    eq(p, g[tag + '_pred']); eq(lm, g[tag + '_lmap']); eq(le, g[tag + '_levid'])
+    p, lm, le = fo.bruteforce_fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['Y'], g['Ye'], g['Ym'],
+                                          g['z'], g['ze'], label_dict=d, lnprior=lp, **kw)
+    eq(p, g[tag + '_fp'])
+    p, lm, le = fo.bruteforce_fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['Y'], g['Ye'], g['Ym'],
+                                          g['z'], g['ze'], label_grid=d.grid, lnprior=lp, **kw)
+    eq(p, g[tag + '_fp_grid'])
+
+
+@pytest.mark.parametrize('tag,kw', [('A', {}), ('B', {'free_scale': True, 'ignore_model_err': True})])
+def test_g9_knn_prior_hook(tag, kw):
+    """k-NN variant of the lprob_func hook (prior read at each object's neighbours)."""
+    g = load_golden('g9_knn_prior_hook')
+    d = demo_dict()
+    feats = fo.knn_train(g['Y'], g['Ye'], 5, 'identity', np.random.RandomState(1))
+    q = fo.knn_query_features(g['X'], g['Xe'], 'identity', np.random.RandomState(2))
+    tab = fo.knn_neighbors_exact(feats, q, 4)
+    lp = np.repeat(g['row'][None, :], len(g['X']), axis=0)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(g['X'].copy(), g['Xe'].copy(), g['Xm'].copy(), g['Y'], g['Ye'], g['Ym'],
+                                                     tab, g['z'], g['ze'], label_dict=d, lnprior=lp, **kw)
+    np.testing.assert_array_equal(rn, g[tag + '_neighbors'])
+    np.testing.assert_array_equal(rnn, g[tag + '_Nneighbors'])
+    eq(rlnp, g[tag + '_lnprob']); eq(rp, g[tag + '_pdfs']); eq(rlm, g[tag + '_lmap']); eq(rle, g[tag + '_levid'])
