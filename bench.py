@@ -32,10 +32,12 @@ SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])   # SDSS ugriz 1-sigm
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (public spec; = FP64 matrix peak)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # algorithmic flops per object-model evaluation (add/mul/div/log/exp = 1, fma = 2)
-FLOPS_FUSED = {"A": 58, "B": 64}
-FLOPS_PASS = {"A": 54, "B": 60}  # one pass (likelihood 50/56 + max,sub,exp,add)
+FLOPS_FUSED = {"A": 58, "B": 64, "Ai": 58, "An": 58, "Bn": 64}
+FLOPS_PASS = {"A": 54, "B": 60, "Ai": 54, "An": 54, "Bn": 60}  # one pass (likelihood 50/56 + max,sub,exp,add)
 
-MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True}}
+MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True},
+         "Ai": {"ignore_model_err": True},
+         "An": {"dim_prior": False}, "Bn": {"free_scale": True, "ignore_model_err": True, "dim_prior": False}}
 
 
 def make_problem(n_obj, n_model, seed):
@@ -118,6 +120,9 @@ def main():
                          "search + subset PDFs (configs[3])")
     ap.add_argument("--mask-frac", type=float, default=0.0,
                     help="fraction of object bands flagged unobserved (exercises the masked kernels)")
+    ap.add_argument("--prior", type=int, default=0,
+                    help="P > 0: add an ln-prior table of P rows (one row index per object) to the "
+                         "fused path (the device form of a custom lprob_func, SURVEY 8f-1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -130,7 +135,7 @@ def main():
     Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank)
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
     cpu1 = cpuall = None
-    if world == 1 and not args.no_cpu and args.workload == "fit_predict":
+    if world == 1 and not args.no_cpu and args.workload == "fit_predict" and not args.prior:
         cpu1 = cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, args.cpu_seconds)
         if (os.cpu_count() or 1) > 1:
             cpuall = cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, min(args.cpu_seconds, 10.0))
@@ -172,7 +177,12 @@ def main():
     if args.gather and world > 1 and backend == "nccl":
         gathered = torch.empty((world * N, G), dtype=torch.float64, device=dev)
     opts, ko = like_opts(kw), kde_opts({})
-    extra = {}
+    prior = None
+    if args.prior > 0:
+        gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
+        d_tab = torch.log_softmax(torch.randn((args.prior, M), dtype=torch.float64, device=dev, generator=gen), dim=1)
+        d_rows = torch.randint(0, args.prior, (N,), dtype=torch.int64, device=dev, generator=gen)
+        prior = (d_tab, args.prior, d_rows)
     if args.workload == "fit":
         d_lnl = torch.empty((N, M), dtype=torch.float64, device=dev)
         d_chi2 = torch.empty((N, M), dtype=torch.float64, device=dev)
@@ -195,7 +205,7 @@ def main():
             eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
             eng.knn_fit_predict(dX, dXe, dXm, d_idx, Kt * kk, opts, ko, pdfs=d_pdf, lmap=d_lm, levid=d_le, n=N)
             return
-        eng.fit_predict(dX, dXe, dXm, opts, ko, d_pdf, d_lm, d_le, n=N)
+        eng.fit_predict_prior(dX, dXe, dXm, opts, ko, prior, d_pdf, d_lm, d_le, n=N)
         if gathered is not None:
             eng.sync()
             dist.all_gather_into_tensor(gathered, d_pdf)
@@ -280,7 +290,7 @@ def main():
                                    "dict KDE on 701-pt grid" % (N, M, args.mode),
                        "n_obj_per_gpu": N, "n_model": M, "n_band": 5, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
-                       "mask_frac": args.mask_frac},
+                       "mask_frac": args.mask_frac, "prior_rows": args.prior},
             "pdfs_per_s": float(world) * N * args.steps / dt,
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in

@@ -44,6 +44,8 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     // An additive ln-prior (PRI) keeps to the ln-space body, which tracks nan / +-inf rows.
     static constexpr int WPOW = (VAR == VAR_FAST && !PRI) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
     static constexpr bool HAS_PRIOR = PRI;
+    // launch geometry preference of the ln-space body (measured, profiles/README.md)
+    static constexpr bool PREF_2x16 = (MODE == 2 && VAR == VAR_FAST) || (MODE != 2 && VAR == VAR_MASKED);
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {

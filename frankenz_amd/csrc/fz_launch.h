@@ -101,14 +101,19 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return 0;
 }
 
-// the weight-space kernel body is used when the source allows it and the dimensionality
-// prior is on (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+// the weight-space kernel body is used for the chi2^(3/2) likelihoods (modes A / Ai, 5 bands,
+// dimensionality prior on); for mode B's chi2^1 the ln-space body measured as fast or faster at
+// every geometry, so it is not instantiated there (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+template <class SRC>
+bool fz_use_wspace(const SRC& src) {
+    if constexpr (SRC::WPOW == 3) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE");
+    return false;
+}
 template <class SRC, int TW, int NW>
 int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    if constexpr (SRC::WPOW != 0) {
-        if (src.lp.dim_prior && !getenv("FZ_NO_WSPACE"))
-            return fz_launch_fused_wm<SRC, TW, NW, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+    if constexpr (SRC::WPOW == 3) {
+        if (fz_use_wspace(src)) return fz_launch_fused_wm<SRC, TW, NW, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
     }
     return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
 }
@@ -132,9 +137,10 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             else r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
             int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
-            // measured best geometry per kernel body (profiles/README.md): the chi2^(3/2) weight-space
-            // body fits 128 VGPRs and likes 4 waves/SIMD; the others want the 256-VGPR budget
-            if (tw == 4 && SRC::WPOW == 3 && src.lp.dim_prior && !getenv("FZ_NO_WSPACE")) { tw = 2; nw = 16; }
+            // measured best geometry per kernel body (profiles/README.md, r1_v4 sweep): the
+            // weight-space body, unmasked mode B and masked modes A / Ai fit 128 VGPRs and like
+            // 16 waves x 2 objects; the rest want the 256-VGPR budget of 8 waves x 4 objects
+            if (tw == 4 && (fz_use_wspace(src) || SRC::PREF_2x16)) { tw = 2; nw = 16; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
