@@ -2,7 +2,7 @@
 //
 // The likelihood path needs log(chi2), exp(lnl - max) and 1/var per object-model
 // pair.  The OCML versions are correctly rounded-ish and cost ~100 / ~50 / ~11
-// fp64 instructions; these cost ~15 / ~17 / ~3 and keep ~1e-15 relative accuracy
+// fp64 instructions; these cost ~15 / ~12 / ~3 and keep ~1e-15 relative accuracy
 // (absolute for log), seven orders of magnitude inside the 1e-5 parity bar.
 // Accuracy is pinned by tests/test_hip_fastmath.py against NumPy.
 #pragma once
@@ -28,16 +28,16 @@ __device__ __forceinline__ double rcp_nr(double v) {
 // ds_read instead of a global load sitting in the vector-memory queue.
 struct FastTabs {
     const double2* logt;     // [128] {1/c, log c}
-    const double* expt;      // [64]  2^(j/64)
+    const double* expt;      // [FZ_EXP_K]  2^(j/FZ_EXP_K)
 };
-#define FZ_TABS_DOUBLES (256 + 64)
+#define FZ_TABS_DOUBLES (256 + FZ_EXP_K)
 __device__ __forceinline__ FastTabs global_tabs() {
     FastTabs t; t.logt = reinterpret_cast<const double2*>(FZ_LOG_TAB); t.expt = FZ_EXP_TAB; return t;
 }
 // copy the tables into LDS at `dst` (FZ_TABS_DOUBLES doubles); caller synchronises
 __device__ __forceinline__ FastTabs stage_tabs(double* dst, int tid, int nthreads) {
     for (int k = tid; k < 256; k += nthreads) dst[k] = FZ_LOG_TAB[k];
-    for (int k = tid; k < 64; k += nthreads) dst[256 + k] = FZ_EXP_TAB[k];
+    for (int k = tid; k < FZ_EXP_K; k += nthreads) dst[256 + k] = FZ_EXP_TAB[k];
     FastTabs t; t.logt = reinterpret_cast<const double2*>(dst); t.expt = dst + 256; return t;
 }
 
@@ -79,46 +79,37 @@ __device__ __forceinline__ double log_pos_t(double x, const FastTabs& tb) {
 __device__ __forceinline__ double log_pos(double x, const FastTabs& tb) { return log_pos_t<false>(x, tb); }
 __device__ __forceinline__ double log_pos(double x) { return log_pos_t<false>(x, global_tabs()); }
 
+// exp(x) for |x| <= 700 (the callers clamp).  n = round(x K/ln2), K = 2048, is read off the low
+// mantissa word of x K/ln2 + 1.5*2^52 (no rint / cvt); r = x - n ln2/K with ONE constant
+// (|r| <= 1.7e-4; the constant is off by 3.4e-17 relative, which puts 3.4e-17 |x| into the
+// result -- a third of the rounding error 1.1e-16 |x| that x itself carries); exp(r) is the
+// Taylor cubic (remainder 3.4e-17); 2^(n mod K / K) from the table; 2^(n div K) is added to the
+// exponent field (the result stays normal for x >= -700).
+// Relative error < 4e-16 + 3.4e-17 |x|  (tests/test_hip_fastmath.py).
+__device__ __forceinline__ double exp_core(double x, const FastTabs& tb) {
+    const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
+    const double d = fma(x, 2954.639443740597, MAGIC);           // K/ln2
+    const double r = fma(d - MAGIC, -0.0003384507717577858, x);  // ln2/K
+    const int n = __double2loint(d);
+    const double t = tb.expt[n & (FZ_EXP_K - 1)];
+    double p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = t * p;                                      // in [1,2): exponent field 1023
+    return __hiloint2double(__double2hiint(v) + ((n >> 11) << 20), __double2loint(v));
+}
 // exp(x) for x <= 0 (what the softmax needs).  Arguments below -700 are clamped, i.e.
 // return exp(-700) ~ 1e-304 instead of underflowing towards 0: harmless for sums of
 // weights (callers never rely on an exact 0) and it keeps 2^q a plain exponent-field
-// add instead of an ldexp.  NaN input is NOT propagated (callers track NaNs
-// separately).  Relative error < 3e-16.
+// add instead of an ldexp.  NaN input is NOT propagated (callers track NaNs separately).
 __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
-    x = fmax(x, -700.0);                                         // also maps NaN -> -700
-    const double k = rint(x * 92.33248261689366);                // 64/ln2
-    double r = fma(k, -0.010830424696249145, x);                 // ln2/64 hi
-    r = fma(k, -3.623510646634843e-19, r);                       // ln2/64 lo  (hi+lo good to 1e-35)
-    const int ki = (int)k;
-    const double t = tb.expt[ki & 63];
-    // 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120, Estrin form (dependency depth 3)
-    const double r2 = r * r;
-    const double p01 = 1.0 + r;
-    const double p23 = fma(r, 1.0 / 6.0, 0.5);
-    const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    double p = fma(r2, fma(r2, p45, p23), p01);
-    const double v = t * p;                                      // in [1,2): exponent field 1023
-    // v * 2^q with q = ki >> 6 in [-1010, 0]: add q to the exponent field
-    return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
+    return exp_core(fmax(x, -700.0), tb);                        // fmax also maps NaN -> -700
 }
 __device__ __forceinline__ double exp_neg(double x) { return exp_neg(x, global_tabs()); }
 
 // exp(x) with x clamped to [-700, 700] (NaN -> -700): same algorithm, either sign.
 __device__ __forceinline__ double exp_clamped(double x, const FastTabs& tb) {
-    x = fmin(fmax(x, -700.0), 700.0);
-    const double k = rint(x * 92.33248261689366);
-    double r = fma(k, -0.010830424696249145, x);
-    r = fma(k, -3.623510646634843e-19, r);
-    const int ki = (int)k;
-    const double t = tb.expt[ki & 63];
-    // 1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120, Estrin form (dependency depth 3)
-    const double r2 = r * r;
-    const double p01 = 1.0 + r;
-    const double p23 = fma(r, 1.0 / 6.0, 0.5);
-    const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    double p = fma(r2, fma(r2, p45, p23), p01);
-    const double v = t * p;
-    return __hiloint2double(__double2hiint(v) + ((ki >> 6) << 20), __double2loint(v));
+    return exp_core(fmin(fmax(x, -700.0), 700.0), tb);
 }
 
 }  // namespace fz
