@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--prior", type=int, default=0,
                     help="P > 0: add an ln-prior table of P rows (one row index per object) to the "
                          "fused path (the device form of a custom lprob_func, SURVEY 8f-1)")
+    ap.add_argument("--wt-thresh", type=float, default=1e-3, help="kde_kwargs wt_thresh (reference default 1e-3)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -176,7 +177,7 @@ def main():
     gathered = None
     if args.gather and world > 1 and backend == "nccl":
         gathered = torch.empty((world * N, G), dtype=torch.float64, device=dev)
-    opts, ko = like_opts(kw), kde_opts({})
+    opts, ko = like_opts(kw), kde_opts({"wt_thresh": args.wt_thresh})
     prior = None
     if args.prior > 0:
         gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)

@@ -44,6 +44,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     // An additive ln-prior (PRI) keeps to the ln-space body, which tracks nan / +-inf rows.
     static constexpr int WPOW = (VAR == VAR_FAST && !PRI) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
     static constexpr bool HAS_PRIOR = PRI;
+    static constexpr int NB = BT;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
     static constexpr bool PREF_2x16 = (MODE == 2 && VAR == VAR_FAST) || (MODE != 2 && VAR == VAR_MASKED);
     PriorView pv;                                 // read only when PRI
@@ -97,6 +98,29 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
         const double* src = (ch < RW * TILE / 2) ? rec + tile * (TILE * RW) + 2 * ch
                                                  : reinterpret_cast<const double*>(P::mv.bits + tile * TILE) + 2 * (ch - RW * TILE / 2);
         return *reinterpret_cast<const double2*>(src);
+    }
+    // record j of the array-of-records copy, j wave-uniform: scalar loads -> SGPR operands (k_ol)
+    __device__ __forceinline__ void load_model_rec(int64_t j, typename P::MR& m) const {
+        const double* r = ((MODE == 0) ? P::mv.rec0 : P::mv.rec1) + j * RW;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            m.y[b] = r[b];
+            if (MODE == 0) m.ye2[b] = r[BT + b];
+        }
+        m.bits = 0xffffffffu;
+    }
+    // the same record for a per-lane j, as 16-byte loads (records are 16-B aligned: RW is even)
+    __device__ __forceinline__ void load_model_rec16(int64_t j, typename P::MR& m) const {
+        const double2* r = reinterpret_cast<const double2*>(((MODE == 0) ? P::mv.rec0 : P::mv.rec1) + j * RW);
+        double v[RW];
+#pragma unroll
+        for (int q = 0; q < RW / 2; ++q) { const double2 w = r[q]; v[2 * q] = w.x; v[2 * q + 1] = w.y; }
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            m.y[b] = v[b];
+            if (MODE == 0) m.ye2[b] = v[BT + b];
+        }
+        m.bits = 0xffffffffu;
     }
     __device__ __forceinline__ void load_model_lds(const double* t, int k, typename P::MR& m) const {
         const double2* r = reinterpret_cast<const double2*>(t + k * RW);

@@ -2,6 +2,7 @@
 #pragma once
 #include "fz_ctx.h"
 #include "fz_kernels.h"
+#include "fz_ol.h"
 
 inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
     using namespace fz;
@@ -118,6 +119,43 @@ int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
 }
 
+// object-per-lane single pass (fz_ol.h); +1 = does not fit, caller takes the k_fused route
+template <class SRC, int OPL>
+int fz_launch_ol(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                 double* lmap, double* levid, double* pdfs) {
+    using namespace fz;
+    const int64_t W = (M + 31) / 32;
+    const int64_t per_block = 4 * 64 * OPL;
+    const int64_t nblk = (n + per_block - 1) / per_block;
+    const size_t mask_bytes = (size_t)(nblk * 4 * OPL) * W * 64 * 4;       // whole waves write whole rows
+    if ((int64_t)mask_bytes > c->ws_limit) return 1;
+    if (c->d_cand.ensure(mask_bytes) != 0) return 1;
+    FZCHK(c->d_olstats.ensure((size_t)n * sizeof(OlStats)));
+    FZCHK(c->d_kv.ensure(sizeof(KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    constexpr int NWV = 8;
+    const size_t lds2 = (size_t)NWV * kv.acc_stride * 8 + (size_t)NWV * FZ_OL_TILE * 4 + (size_t)NWV * FZ_OL_SEG * 2;
+    if (lds2 > 160 * 1024) return 1;
+    auto k1 = k_ol<SRC, OPL>;
+    auto k2 = k_ol_pdf<SRC, NWV>;
+    HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    {
+        Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+        hipLaunchKernelGGL(k1, dim3((unsigned)nblk), dim3(256), 0, c->stream, src, n, (int)M, ko->wt_thresh,
+                           c->d_cand.as<uint32_t>(), c->d_olstats.as<OlStats>());
+    }
+    HIPCHK(hipGetLastError());
+    {
+        Timer t(c, &c->tm.ms_kde, &c->tm.n_kde);
+        hipLaunchKernelGGL(k2, dim3((unsigned)((n + NWV - 1) / NWV)), dim3(NWV * 64), lds2, c->stream, src, c->d_kv.as<KdeView>(),
+                           kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<uint32_t>(),
+                           c->d_olstats.as<OlStats>(), lmap, levid, pdfs);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // fit_predict on a prepared chunk: single pass when possible, else two passes
 template <class SRC>
 int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap,
@@ -127,7 +165,13 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
     if (!c->force_twopass) {
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
-        int r;
+        int r = 1;
+        if constexpr (SRC::WPOW == 3) {
+            if (fz_use_wspace(src) && getenv("FZ_OL")) {
+                r = fz_launch_ol<SRC, 2>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                if (r <= 0) return r;
+            }
+        }
         if constexpr (SRC::TILE < 256) {
             // wide records (17-32 bands): one object per wave keeps the kernel inside the register file
             r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);

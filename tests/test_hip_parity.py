@@ -369,3 +369,27 @@ def test_more_than_32_bands_is_refused():
     Y = np.ones((10, 33))
     with pytest.raises(Exception, match='bands unsupported'):
         BruteForce(Y, 0.1 * Y, np.ones_like(Y)).fit(Y[:2].copy(), Y[:2].copy(), np.ones((2, 33)), verbose=False)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}])
+def test_object_per_lane_path_matches(kw, monkeypatch):
+    """FZ_OL=1 routes the unmasked 5-band chi2^(3/2) likelihoods through the object-per-lane
+    kernels (fz_ol.h): same PDFs / lmap / levid as the default path and as the oracle,
+    including self matches (chi2 == 0) and more objects than one wave holds."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(77)
+    M, N, B = 1500, 300, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    X[:20] = Y[:20]; Xe[:20] = Ye[:20]                     # exact self matches
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    p0, (lm0, le0) = run()
+    monkeypatch.setenv('FZ_OL', '1')
+    p1, (lm1, le1) = run()
+    monkeypatch.delenv('FZ_OL')
+    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:60].copy(), Xe[:60].copy(), Xm[:60].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(p1[:60], rp, rtol=1e-8, atol=1e-14); close(lm1[:60], rlm); close(le1[:60], rle)
