@@ -8,6 +8,7 @@
 #include "fz_knn.h"
 #include "fz_launch.h"
 #include "fz_modec.h"
+#include "fz_summary.h"
 
 using namespace fz;
 
@@ -681,3 +682,4 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
 }
 
 #include "fz_knn_host.inc"
+#include "fz_summary_host.inc"

@@ -187,6 +187,18 @@ class Engine(object):
         check(self.lib.fz_knn_predict_logwt(self.h, ptr(logwt), ptr(neighbors), ptr(nnbr), n, int(W),
                                             C.byref(kopts), ptr(pdfs), ptr(lmap), ptr(levid)))
 
+    def pdfs_summarize(self, pdfs, pgrid, renormalize, urand, loss, widths, wscale, stats, n=None):
+        n = len(pdfs) if n is None else n
+        check(self.lib.fz_pdfs_summarize(self.h, ptr(pdfs), n, len(pgrid), ptr(pgrid), int(bool(renormalize)),
+                                         ptr(urand), ptr(loss), ptr(widths), float(wscale), ptr(stats)))
+
+    def overlap_nz(self, pdfs, nz, pair, step, overlap, n=None):
+        n = len(pdfs) if n is None else n
+        out = np.zeros(1)
+        pi, pj = (-1, -1) if pair is None else (int(pair[0]), int(pair[1]))
+        check(self.lib.fz_overlap_nz(self.h, ptr(pdfs), n, len(nz), ptr(nz), pi, pj, float(step), ptr(overlap), ptr(out)))
+        return float(out[0])
+
     def clean(self, x, xe, xm):
         check(self.lib.fz_clean(self.h, ptr(x), ptr(xe), ptr(xm), x.shape[0], x.shape[1]))
 

@@ -17,7 +17,7 @@ import numpy as np
 from .engine import HostObjects, get_engine, kde_opts, like_opts
 
 __all__ = ["loglike", "logprob", "logprob_prior", "gaussian", "gauss_kde", "gauss_kde_dict",
-           "magnitude", "luptitude", "PDFDict"]
+           "magnitude", "luptitude", "PDFDict", "pdfs_summarize"]
 
 
 def _ndim_dtype(data_mask, models_mask):
@@ -220,3 +220,53 @@ def luptitude(phot, err, skynoise=1., zeropoints=1., *args, **kwargs):
     mag_err = np.sqrt(np.square(2.5 * np.log10(np.e) * err)
                       / (np.square(2. * skynoise) + np.square(phot)))
     return mag, mag_err
+
+
+def _default_wconf(point):
+    return (1. + point) * 0.03
+
+
+def pdfs_summarize(pdfs, pgrid, renormalize=True, rstate=None, pkern='lorentz', pkern_grid=None,
+                   wconf_func=None, device=None):
+    """PDF summary statistics (pdf.py:899-1074): mean / median / mode / "best" estimators
+    with their std, conf and risk, the 68 % / 95 % credible bounds and a Monte-Carlo
+    draw.  Same signature and return tuple as the reference; ``pdfs`` is renormalised
+    in place.  The (G,G) loss kernel is a host-side table (pdf.py:1003-1023); the
+    (N,G)x(G,G) risk product, the CDFs and every per-object reduction run on the GPU.
+    A custom ``wconf_func`` is evaluated on the host (once per estimator and object,
+    like the reference) between two device passes."""
+    if rstate is None:
+        rstate = np.random
+    if not isinstance(pdfs, np.ndarray) or pdfs.dtype != np.float64 or not pdfs.flags.c_contiguous:
+        raise ValueError("`pdfs` must be a C-contiguous float64 array (it is renormalised in place)")
+    pgrid_a = np.ascontiguousarray(pgrid, dtype=np.float64)
+    Nobj, Ngrid = len(pdfs), len(pgrid_a)
+    if pdfs.shape != (Nobj, Ngrid):
+        raise ValueError("`pdfs` must have shape (Npdf, len(pgrid))")
+    # kernel over (truth, guess) pairs, exactly as pdf.py:1003-1023
+    if pkern_grid is None:
+        ptrue = pgrid_a.reshape(Ngrid, 1)
+        pguess = pgrid_a.reshape(1, Ngrid)
+        pkern_grid = (ptrue - pguess) / ((1. + ptrue) * 0.15)
+    if isinstance(pkern, str) and pkern == 'tophat':
+        kernel = (np.square(pkern_grid) < 1.)
+    elif isinstance(pkern, str) and pkern == 'gaussian':
+        kernel = np.exp(-0.5 * np.square(pkern_grid))
+    elif isinstance(pkern, str) and pkern == 'lorentz':
+        kernel = 1. / (1. + np.square(pkern_grid))
+    else:
+        try:
+            kernel = pkern(pkern_grid)
+        except Exception:
+            raise RuntimeError("The input kernel does not appear to be valid.")
+    loss = np.ascontiguousarray(1.0 - kernel, dtype=np.float64)
+    urand = np.array([rstate.rand() for _ in range(Nobj)], dtype=np.float64)      # pdf.py:1000, one draw per object
+    eng = get_engine(device)
+    stats = np.empty((21, Nobj))
+    eng.pdfs_summarize(pdfs, pgrid_a, renormalize, urand, loss, None, 0.03, stats)
+    if wconf_func is not None:
+        widths = np.array([[wconf_func(stats[4 * e, i]) for e in range(4)] for i in range(Nobj)], dtype=np.float64)
+        eng.pdfs_summarize(pdfs, pgrid_a, False, urand, loss, np.ascontiguousarray(widths), 0.03, stats)
+    s = stats
+    return ((s[0], s[1], s[2], s[3]), (s[4], s[5], s[6], s[7]), (s[8], s[9], s[10], s[11]),
+            (s[12], s[13], s[14], s[15]), (s[16], s[17], s[18], s[19]), s[20])

@@ -176,6 +176,25 @@ int  fz_knn_predict_logwt(fz_ctx* ctx, const double* logwt, const int64_t* neigh
                           const int64_t* nnbr, int64_t N, int64_t W, const fz_kde_opts* kde,
                           double* pdfs, double* lmap, double* levid);
 
+/* ---- consumers of the PDF stack ---- */
+/* pdf.pdfs_summarize (pdf.py:899-1074).  pdfs (N,G) is renormalised IN PLACE when
+ * renormalize != 0 (pdf.py:984-985).  urand (N): the rstate.rand() of each object
+ * (pdf.py:1000), drawn by the caller so that the stream is the reference's.  loss
+ * (G,G): 1 - kernel over (truth, guess) (pdf.py:1003-1024).  widths (N,4) or NULL:
+ * the wconf_func windows around mean/median/mode/best; NULL means the default
+ * (1 + point) * wconf_scale (pdf.py:1041-1043, 0.03).  stats (21,N) rows:
+ * mean{value,std,conf,risk}, median{..}, mode{..}, best{..}, low95, low68, high68,
+ * high95, Monte-Carlo draw -- the reference's return tuple flattened. */
+int  fz_pdfs_summarize(fz_ctx* ctx, double* pdfs, int64_t N, int64_t G, const double* pgrid,
+                       int32_t renormalize, const double* urand, const double* loss,
+                       const double* widths, double wconf_scale, double* stats);
+/* samplers.loglike_nz (samplers.py:23-86) for finite non-negative nz: overlap (N) =
+ * pdfs @ nz + pair_step * (pdfs[:,i] - pdfs[:,j]) (pair_i < 0: no pair), lnlike =
+ * sum(log(overlap)). */
+int  fz_overlap_nz(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const double* nz,
+                   int64_t pair_i, int64_t pair_j, double pair_step, double* overlap,
+                   double* lnlike);
+
 /* diagnostic: evaluate one of the library's device math helpers elementwise
  * (which: 0 v_rcp_f64 seed, 1 / 2 rcp with one / two Newton steps, 3 log_pos,
  * 4 exp_neg).  Used by tests to pin their accuracy against NumPy. */

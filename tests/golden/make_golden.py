@@ -449,6 +449,43 @@ def g9():
     save('g9_knn_prior_hook', **out)
 
 
+def g10():
+    """pdfs_summarize (pdf.py:899-1074) and the population overlap likelihood
+    (samplers.py:23-86) on the fused PDFs of the g5 problem plus some hand-made shapes
+    (bimodal, edge-peaked, single-bin, flat)."""
+    from frankenz import samplers
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(505, 20, 160)
+    d = demo_dict()
+    bf = BruteForce(Y, Ye, Ym)
+    pd = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, verbose=False, save_fits=False)
+    pd = pd[np.isfinite(pd).all(axis=1)]
+    g = d.grid
+    extra = [0.6 * rpdf.gaussian(0.5, 0.05, g) + 0.4 * rpdf.gaussian(2.2, 0.2, g),
+             rpdf.gaussian(0.0, 0.03, g), rpdf.gaussian(7.0, 0.1, g), np.ones_like(g),
+             (np.arange(len(g)) == 350).astype(float), rpdf.gaussian(3.0, 1.5, g) * 7.3]
+    pdfs = np.vstack([pd, np.array(extra)])
+    out = dict(pdfs_in=pdfs.copy(), grid=g)
+    for kern in ('lorentz', 'gaussian', 'tophat'):
+        rs = np.random.RandomState(10)
+        work = pdfs.copy()
+        res = rpdf.pdfs_summarize(work, g, rstate=rs, pkern=kern)
+        out[kern + '_pdfs_after'] = work
+        flat = [a for grp in res[:5] for a in grp] + [res[5]]
+        out[kern + '_stats'] = np.array(flat)                 # (21, N)
+    out['urand'] = np.random.RandomState(10).rand(len(pdfs))
+    work = pdfs.copy()
+    res = rpdf.pdfs_summarize(work, g, renormalize=False, rstate=np.random.RandomState(10))
+    out['noren_stats'] = np.array([a for grp in res[:5] for a in grp] + [res[5]])
+    # population overlap likelihood
+    norm = pdfs / pdfs.sum(axis=1)[:, None]
+    nz = norm.sum(axis=0) / norm.sum()
+    ll, ov = samplers.loglike_nz(nz, norm, return_overlap=True)
+    out['nz'], out['nz_lnlike'], out['nz_overlap'] = nz, ll, ov
+    ll2, ov2 = samplers.loglike_nz(nz, norm, return_overlap=True, pair=(120, 300), pair_step=1e-4)
+    out['nz_pair_lnlike'], out['nz_pair_overlap'] = ll2, ov2
+    save('g10_summarize', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for nm in sys.argv[1:]:

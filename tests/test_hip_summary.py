@@ -1,0 +1,89 @@
+"""GPU parity of the PDF-stack consumers: pdf.pdfs_summarize with its
+fp64-MFMA risk product, and samplers.loglike_nz -- against the reference (golden g10) and the
+oracle on larger seeded stacks."""
+import numpy as np
+import pytest
+
+import frankenz_oracle as fo
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def flat(res):
+    return np.array([a for grp in res[:5] for a in grp] + [res[5]])
+
+
+ROWS = ['mean', 'mean_std', 'mean_conf', 'mean_risk', 'med', 'med_std', 'med_conf', 'med_risk', 'mode', 'mode_std',
+        'mode_conf', 'mode_risk', 'best', 'best_std', 'best_conf', 'best_risk', 'low95', 'low68', 'high68', 'high95', 'mc']
+
+
+def check(got, want, rtol=1e-10, atol=1e-12):
+    for r, name in enumerate(ROWS):
+        np.testing.assert_allclose(got[r], want[r], rtol=rtol, atol=atol, err_msg=name, equal_nan=True)
+
+
+@pytest.mark.parametrize('kern', ['lorentz', 'gaussian', 'tophat'])
+def test_g10_summarize_golden(kern):
+    from frankenz_amd.pdf import pdfs_summarize
+    g = load_golden('g10_summarize')
+    work = g['pdfs_in'].copy()
+    res = pdfs_summarize(work, g['grid'], rstate=np.random.RandomState(10), pkern=kern)
+    check(flat(res), g[kern + '_stats'])
+    np.testing.assert_allclose(work, g[kern + '_pdfs_after'], rtol=1e-14, atol=0)       # renormalised in place
+    work = g['pdfs_in'].copy()
+    res = pdfs_summarize(work, g['grid'], renormalize=False, rstate=np.random.RandomState(10))
+    check(flat(res), g['noren_stats'])
+    np.testing.assert_array_equal(work, g['pdfs_in'])
+
+
+def test_summarize_larger_stack_custom_kernel_and_window():
+    """N not a multiple of the GEMM tile, a grid that is not the demo's, a callable kernel, a
+    custom wconf_func."""
+    from frankenz_amd.pdf import pdfs_summarize
+    rs = np.random.RandomState(4)
+    N, G = 777, 333
+    grid = np.linspace(0.0, 4.0, G)
+    mu = rs.uniform(0.1, 3.9, N)[:, None]; sg = rs.uniform(0.02, 0.6, N)[:, None]
+    pd = np.exp(-0.5 * ((grid[None, :] - mu) / sg) ** 2) + 0.3 * np.exp(-0.5 * ((grid[None, :] - (4 - mu)) / (0.5 * sg)) ** 2)
+    pd[rs.rand(N, G) < 0.2] = 0.0                                     # plateaus in the CDFs
+    pd[5] = 0.0; pd[5, 17] = 2.0                                       # single-bin PDF
+    kern = lambda x: np.exp(-np.abs(x))
+    wfun = lambda p: 0.02 + 0.05 * p
+    u = np.random.RandomState(9).rand(N)
+    a = pd.copy(); b = pd.copy()
+    got = flat(pdfs_summarize(a, grid, rstate=np.random.RandomState(9), pkern=kern, wconf_func=wfun))
+    # oracle with the same kernel and window (wconf passed through explicit widths)
+    res = fo.pdfs_summarize(b, grid, urand=u, pkern=kern)
+    want = flat(res)
+    cdfs = b.cumsum(axis=1)
+    for e in range(4):
+        est = want[4 * e]
+        w = wfun(est)
+        want[4 * e + 2] = [fo.interp_rows([est[i] + w[i]], grid, cdfs[i])[0] - fo.interp_rows([est[i] - w[i]], grid, cdfs[i])[0]
+                           for i in range(N)]
+    # "best" is an arg-min over a GEMM row: equal up to summation order, so compare where it is decisive
+    risk = np.dot(b, fo.loss_matrix(grid, kern))
+    srt = np.sort(risk, axis=1)
+    decisive = (srt[:, 1] - srt[:, 0]) > 1e-9 * np.abs(srt[:, 0])
+    assert decisive.mean() > 0.9
+    check(got[:, decisive], want[:, decisive], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(a, b, rtol=1e-14, atol=0)
+
+
+def test_loglike_nz_golden_and_device_stack():
+    from conftest import DevArray
+    from frankenz_amd.samplers import loglike_nz
+    g = load_golden('g10_summarize')
+    norm = np.ascontiguousarray(g['pdfs_in'] / g['pdfs_in'].sum(axis=1)[:, None])
+    ll, ov = loglike_nz(g['nz'], norm, return_overlap=True)
+    np.testing.assert_allclose(ll, g['nz_lnlike'], rtol=1e-13); np.testing.assert_allclose(ov, g['nz_overlap'], rtol=1e-13)
+    ll, ov = loglike_nz(g['nz'], norm, return_overlap=True, pair=(120, 300), pair_step=1e-4)
+    np.testing.assert_allclose(ll, g['nz_pair_lnlike'], rtol=1e-13); np.testing.assert_allclose(ov, g['nz_pair_overlap'], rtol=1e-13)
+    assert loglike_nz(-g['nz'], norm) == -np.inf
+    # a larger stack that stays in device memory
+    rs = np.random.RandomState(6)
+    big = rs.dirichlet(np.full(701, 0.2), size=5000)
+    nz = big.sum(axis=0) / big.sum()
+    ll = loglike_nz(nz, DevArray(big))
+    np.testing.assert_allclose(ll, fo.loglike_nz(nz, big)[0], rtol=1e-13)

@@ -279,3 +279,29 @@ def test_g9_knn_prior_hook(tag, kw):
     np.testing.assert_array_equal(rn, g[tag + '_neighbors'])
     np.testing.assert_array_equal(rnn, g[tag + '_Nneighbors'])
     eq(rlnp, g[tag + '_lnprob']); eq(rp, g[tag + '_pdfs']); eq(rlm, g[tag + '_lmap']); eq(rle, g[tag + '_levid'])
+
+
+@pytest.mark.parametrize('kern', ['lorentz', 'gaussian', 'tophat'])
+def test_g10_pdfs_summarize(kern):
+    """pdf.pdfs_summarize (pdf.py:899-1074) incl. the in-place renormalisation."""
+    g = load_golden('g10_summarize')
+    work = g['pdfs_in'].copy()
+    res = fo.pdfs_summarize(work, g['grid'], urand=g['urand'], pkern=kern)
+    flat = np.array([a for grp in res[:5] for a in grp] + [res[5]])
+    eq(flat, g[kern + '_stats'])
+    np.testing.assert_array_equal(work, g[kern + '_pdfs_after'])
+    # the oracle's own interp restatement against numpy's
+    rs = np.random.RandomState(3)
+    xp = np.cumsum(rs.rand(50) * (rs.rand(50) > 0.3)); fp = rs.randn(50)
+    x = np.concatenate([rs.uniform(-1, xp[-1] + 1, 200), xp[::7], [np.nan]])
+    np.testing.assert_array_equal(fo.interp_rows(x, xp, fp), np.interp(x, xp, fp))
+
+
+def test_g10_loglike_nz():
+    g = load_golden('g10_summarize')
+    norm = g['pdfs_in'] / g['pdfs_in'].sum(axis=1)[:, None]
+    ll, ov = fo.loglike_nz(g['nz'], norm)
+    eq(ll, g['nz_lnlike']); eq(ov, g['nz_overlap'])
+    ll, ov = fo.loglike_nz(g['nz'], norm, (120, 300), 1e-4)
+    eq(ll, g['nz_pair_lnlike']); eq(ov, g['nz_pair_overlap'])
+    assert fo.loglike_nz(-g['nz'], norm)[0] == -np.inf
