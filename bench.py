@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--nmodel", type=int, default=100000)
     ap.add_argument("--mode", choices=sorted(MODES), default="A")
     ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of PDF shards")
-    ap.add_argument("--workload", choices=["fit_predict", "fit", "knn"], default="fit_predict",
+    ap.add_argument("--workload", choices=["fit_predict", "fit", "knn", "summarize"], default="fit_predict",
                     help="fit_predict: headline fused path (default). fit: materialising BruteForce.fit "
                          "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). knn: KMCkNN "
                          "search + subset PDFs (configs[3])")
@@ -198,7 +198,20 @@ def main():
         dQ = torch.from_numpy(q).to(dev)
         d_idx = torch.empty((N, Kt * kk), dtype=torch.int64, device=dev)
 
+    if args.workload == "summarize":
+        # pdf.pdfs_summarize on the PDFs of one fused pass (device-resident stack)
+        eng.fit_predict(dX, dXe, dXm, opts, ko, d_pdf, d_lm, d_le, n=N)
+        gt = np.asarray(pd.grid, dtype=np.float64)
+        kg = (gt[:, None] - gt[None, :]) / ((1. + gt[:, None]) * 0.15)          # host-side (G,G) table, pdf.py:1003-1023
+        d_loss = torch.from_numpy(np.ascontiguousarray(1.0 - 1. / (1. + np.square(kg)))).to(dev)
+        d_u = torch.rand(N, dtype=torch.float64, device=dev)
+        d_stats = torch.empty((21, N), dtype=torch.float64, device=dev)
+        grid_np = np.ascontiguousarray(pd.grid, dtype=np.float64)
+
     def step():
+        if args.workload == "summarize":
+            eng.pdfs_summarize(d_pdf, grid_np, True, d_u, d_loss, None, 0.03, d_stats, n=N)
+            return
         if args.workload == "fit":
             eng.fit(dX, dXe, dXm, opts, d_lnl, d_chi2, n=N)
             return
@@ -240,6 +253,16 @@ def main():
         ok = bool(torch.isfinite(s).all().item()) and float((s - 1).abs().max().item()) < 1e-9
     if args.workload != "fit_predict" and rank == 0:
         # secondary workloads: their own JSON line (not the driver's headline contract)
+        if args.workload == "summarize":
+            flops = 2.0 * N * G * G * args.steps
+            print(json.dumps({"metric": "pdfs_summarize objects/sec (risk GEMM N x G x G fp64 MFMA + per-object statistics)",
+                              "value": world * N * args.steps / dt, "unit": "objects/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "pdf.pdfs_summarize: %d PDFs x %d grid points, lorentz kernel" % (N, G)},
+                              "roofline": {"bound": "mfma", "kernel": "k_gemm_f64", "achieved": flops / dt / 1e12,
+                                           "peak": 78.6, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 78.6,
+                                           "note": "whole call (normalise + GEMM + statistics) over the GEMM's 2 N G^2 flops"}}))
+            return
         if args.workload == "fit":
             ms = tm["ms_planes"] / max(tm["n_planes"], 1)
             per_launch = N * M / (max(tm["n_planes"], 1) / args.steps)

@@ -11,6 +11,21 @@
 
 namespace fz {
 
+// max(a, b) as the bare v_max_f64 (IEEE mode: a quiet NaN operand yields the other one).
+// fmax() makes the compiler canonicalise any operand it cannot prove quiet-NaN-free -- an
+// extra v_max_f64 x, x per call on loop-carried values; the hot loops use this instead.
+__device__ __forceinline__ double vmax_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double vmin_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // 1/v: hardware v_rcp_f64 seed + NITER Newton steps (each 2 FMAs).
 template <int NITER>
 __device__ __forceinline__ double rcp_nr(double v) {
@@ -103,13 +118,13 @@ __device__ __forceinline__ double exp_core(double x, const FastTabs& tb) {
 // weights (callers never rely on an exact 0) and it keeps 2^q a plain exponent-field
 // add instead of an ldexp.  NaN input is NOT propagated (callers track NaNs separately).
 __device__ __forceinline__ double exp_neg(double x, const FastTabs& tb) {
-    return exp_core(fmax(x, -700.0), tb);                        // fmax also maps NaN -> -700
+    return exp_core(vmax_raw(x, -700.0), tb);                    // also maps NaN -> -700
 }
 __device__ __forceinline__ double exp_neg(double x) { return exp_neg(x, global_tabs()); }
 
 // exp(x) with x clamped to [-700, 700] (NaN -> -700): same algorithm, either sign.
 __device__ __forceinline__ double exp_clamped(double x, const FastTabs& tb) {
-    return exp_core(fmin(fmax(x, -700.0), 700.0), tb);
+    return exp_core(vmin_raw(vmax_raw(x, -700.0), 700.0), tb);
 }
 
 }  // namespace fz

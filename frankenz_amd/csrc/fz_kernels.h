@@ -504,7 +504,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
         for (int o = 0; o < TW; ++o) {
             const double e = exp_clamped(t[o], tb);
             if (WP == 3) {
-                const double cc = fmax(c2[o], 1e-300);           // chi2 == 0 (self match): w -> 0, no 0*inf
+                const double cc = c2[o] + 1e-300;                // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
                 const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
                 double sq = cc * y;                              // ~sqrt(cc)
                 const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
@@ -515,7 +515,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
             }
             if (TAIL) w[o] = (j < M) ? w[o] : 0.0;
             ws.s[o] += w[o];
-            ws.wmax[o] = fmax(ws.wmax[o], w[o]);
+            ws.wmax[o] = vmax_raw(ws.wmax[o], w[o]);
         }
 #pragma unroll
         for (int o = 0; o < TW; ++o) {

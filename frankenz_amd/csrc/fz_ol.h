@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_ol(SRC src_, int64_t N, int M, double w
         const uint32_t bit = 1u << (j & 31);
 #pragma unroll
         for (int o = 0; o < OPL; ++o) {
-            const double e = exp_core(fmax(t[o], -700.0), tb);
+            const double e = exp_core(vmax_raw(t[o], -700.0), tb);
             const double cc = c2[o] + 1e-300;                    // chi2 == 0 (self match): w -> 0, no 0*inf
             const double y = __builtin_amdgcn_rsq(cc);
             double sq = cc * y;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_ol(SRC src_, int64_t N, int M, double w
             sq = fma(sq, r, sq);
             const double w = (c2[o] * sq) * e;
             s[o] += w;
-            wmax[o] = fmax(wmax[o], w);
+            wmax[o] = vmax_raw(wmax[o], w);
             bits[o] |= (w > wmax[o] * thrf) ? bit : 0u;          // superset of wt > wt_thresh * max(wt): the max only grows
         }
         if ((j & 31) == 31 || j == M - 1) {
