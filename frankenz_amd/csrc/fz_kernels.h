@@ -378,7 +378,7 @@ struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 s
 // TW x cap entries (cap = M: it can never overflow).
 //
 // A pair is recorded when its lnl is within the weight threshold of the best lnl
-// seen SO FAR (per lane, tightened every 16 steps with the wave-wide best): a
+// seen SO FAR (per lane, tightened every 64 steps with the wave-wide best): a
 // superset of the pairs with wt > wt_thresh * max(wt), because the running best only
 // grows.  The exact test (pdf.py:510 / 591, strict >) is applied afterwards with the
 // final max and evidence, then the kernels are stacked and the PDF normalised.
@@ -431,10 +431,10 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
                 fs.cnt[o] += __builtin_popcountll(mask);
             }
         }
-        // every 16 steps re-reference each lane's (max, sum) to the wave-wide best, so
+        // every 64 steps re-reference each lane's (max, sum) to the wave-wide best, so
         // that the candidate filter works against the best lnl any lane has seen (the
         // sum is rescaled accordingly: exact)
-        if ((++fs.tick & 15) == 0) {
+        if ((++fs.tick & 63) == 0) {
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
                 const double mx = wave_max(fs.st[o].m);
@@ -448,7 +448,7 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
 // ---- weight-space variant of the tile step (SRC::WPOW != 0, dim_prior on) ----------
 // w = exp(lnl - ref) = chi2^(WPOW/2) exp(-chi2/2 - lg - ref) is formed directly: one
 // exp, one rsqrt, no log, no selects.  `ref` (wave-uniform per object) is re-based on
-// the wave-wide best every 16 steps, and at once if a pair would overflow the range.
+// the wave-wide best every 64 steps, and at once if a pair would overflow the range.
 // Candidates carry chi2; their exact lnl is recomputed in the PDF stage.
 template <int TW>
 struct WState {
@@ -528,7 +528,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                 ws.cnt[o] += __builtin_popcountll(mask);
             }
         }
-        if ((++ws.tick & 15) == 0) {
+        if ((++ws.tick & 63) == 0) {
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
                 const double wm = wave_max(ws.wmax[o]);

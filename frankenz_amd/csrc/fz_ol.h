@@ -2,7 +2,7 @@
 //
 // k_fused gives a lane a MODEL and keeps the wave's few objects wave-uniform; every step
 // then re-reads the model record and the object rows from LDS, and the per-object softmax
-// state lives across lanes (wave reductions, a re-base every 16 steps, a block barrier per
+// state lives across lanes (wave reductions, a re-base every 64 steps, a block barrier per
 // tile).  Here the roles are swapped: a lane owns OPL OBJECTS for the whole kernel (their
 // fluxes / variances and running statistics sit in its VGPRs) and the models stream past as
 // wave-uniform values -- scalar loads of the model records, SGPR operands to the fp64 ALU.
