@@ -87,7 +87,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     // RW doubles) followed by the TILE mask words: a contiguous slice of the record
     // array, staged with plain 16-B-per-lane copies.  RW*8 is 16 mod 32 bytes, which
     // makes a wave's ds_read_b128 of 64 consecutive records bank-conflict free.
-    static constexpr int TILE = (BT > 16) ? 64 : 256;           // wide records: smaller tiles (LDS)
+    static constexpr int TILE = (BT > 16) ? 64 : 256;           // wide records: smaller tiles (LDS); 512 measured slower (staging registers)
     static constexpr int NVAL = BT + (MODE == 0 ? BT : 0);
     static constexpr int RW = NVAL + ((6 - NVAL % 4) % 4);          // smallest width >= NVAL that is 2 mod 4
     static_assert(RW >= NVAL && RW % 4 == 2, "record width must be 2 mod 4 doubles (16 mod 32 bytes)");

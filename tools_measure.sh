@@ -1,0 +1,17 @@
+#!/bin/bash
+# Full measurement set for profiles/ (run through gpurun; writes gpurun_out/m_*).
+#   ./tools_measure.sh
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+python3 bench.py > $O/m_bench_fit_predict_modeA.json 2> $O/m_bench_fit_predict_modeA.err
+python3 bench.py --mode B --no-cpu > $O/m_bench_fit_predict_modeB.json 2>/dev/null
+python3 bench.py --mode Ai --no-cpu > $O/m_bench_fit_predict_modeAi.json 2>/dev/null
+python3 bench.py --mode A --mask-frac 0.02 --no-cpu > $O/m_bench_fit_predict_masked.json 2>/dev/null
+python3 bench.py --mode A --prior 64 --no-cpu > $O/m_bench_fit_predict_prior.json 2>/dev/null
+python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 > $O/m_bench_fit_planes.json 2>/dev/null
+python3 bench.py --workload knn --nobj 100000 --no-cpu > $O/m_bench_knn.json 2>/dev/null
+python3 bench.py --workload summarize --nobj 1000000 --no-cpu > $O/m_bench_summarize.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_headline -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/m_stats_headline.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_summarize -- python3 bench.py --workload summarize --nobj 1000000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_summarize.log 2>&1
+tail -c 600 $O/m_bench_fit_predict_modeA.json

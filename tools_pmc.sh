@@ -26,7 +26,7 @@ for d in sorted(glob.glob('gpurun_out/pmc_*/')):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
             if 'fz::' not in k: continue
-            k = k.split('(')[0][-40:]
+            k = k.split('(')[0].replace('void fz::', '')[:60]
             agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
         for k in agg:
             for c in agg[k]:
