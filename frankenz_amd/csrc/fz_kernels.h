@@ -93,11 +93,13 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static_assert(RW >= NVAL && RW % 4 == 2, "record width must be 2 mod 4 doubles (16 mod 32 bytes)");
     static constexpr int TILE_DOUBLES = RW * TILE + (P::MASKED ? TILE / 2 : 0);
     static constexpr int NCHUNK = TILE_DOUBLES / 2;                 // 16-byte chunks
-    __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
+    __device__ __forceinline__ const double* tile_chunk_ptr(int64_t tile, int ch) const {
         const double* rec = (MODE == 0) ? P::mv.rec0 : P::mv.rec1;
-        const double* src = (ch < RW * TILE / 2) ? rec + tile * (TILE * RW) + 2 * ch
-                                                 : reinterpret_cast<const double*>(P::mv.bits + tile * TILE) + 2 * (ch - RW * TILE / 2);
-        return *reinterpret_cast<const double2*>(src);
+        return (ch < RW * TILE / 2) ? rec + tile * (TILE * RW) + 2 * ch
+                                    : reinterpret_cast<const double*>(P::mv.bits + tile * TILE) + 2 * (ch - RW * TILE / 2);
+    }
+    __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
+        return *reinterpret_cast<const double2*>(tile_chunk_ptr(tile, ch));
     }
     // record j of the array-of-records copy, j wave-uniform: scalar loads -> SGPR operands (k_ol)
     __device__ __forceinline__ void load_model_rec(int64_t j, typename P::MR& m) const {
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(256) void k_kde(SRC src_, KdeView kv, int64_t N, in
     }
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
 // ---- single pass: likelihood + softmax statistics + candidates -> PDF -----------
 struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 store
 
@@ -588,20 +593,43 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             else { ms_init(fs.st[o]); fs.cnt[o] = 0; }
             src.park_obj(i0 + o < N ? i0 + o : N - 1, objs + o * OD, lane);
         }
-        // tile 0 -> LDS
+        // tile 0 -> LDS.  Two staging forms, chosen per kernel body from measurements
+        // (profiles/README.md): the ln-space bodies copy tiles with the LDS-DMA form of the load
+        // (global_load_lds_dwordx4: 16 B per lane, destination = wave-uniform base + lane * 16,
+        // which is exactly this contiguous copy) -- no staging registers in kernels that sit at
+        // their VGPR cap, no ds_write pass, drained by __syncthreads() (vmcnt(0)); the
+        // weight-space body keeps register staging (loads issued before, parked after the
+        // compute of the current tile), which measured 2-4 % faster there.
+        constexpr bool GLDS = !WM;
+        auto stage_tile = [&](int tile, double* dstbuf) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int ch = tid + q * NT;
+                if (ch < NCH)
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src.tile_chunk_ptr(tile, ch),
+                                                     (lds_void*)(dstbuf + 2 * (q * NT + wave * 64)), 16, 0, 0);
+            }
+        };
         double2 stage[CPT];
+        if (GLDS) {
+            stage_tile(0, smem);
+        } else {
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(0, ch); }
+            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(0, ch); }
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
+            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
+        }
         __syncthreads();
         for (int t = 0; t < ntiles; ++t) {
             const double* cur = smem + (t & 1) * TD;
             double* nxt = smem + ((t + 1) & 1) * TD;
             const bool more = t + 1 < ntiles;
-            if (more) {                                           // issue next tile's loads early ...
+            if (more) {                                           // next tile: in flight while the current one is used
+                if (GLDS) stage_tile(t + 1, nxt);
+                else {
 #pragma unroll
-                for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
+                    for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
+                }
             }
             if (work && WM) {
                 if constexpr (WM) {
@@ -617,7 +645,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                     else fused_tile<SRC, TW, 0, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 }
             }
-            if (more) {                                           // ... and park them in the other buffer late
+            if (more && !GLDS) {                                  // ... and parked in the other buffer late
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(nxt)[ch] = stage[q]; }
             }
