@@ -427,7 +427,9 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
         }
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const bool c = l[o] >= fs.st[o].m + lt;                       // >=: lt may be absorbed when |lnl| is huge; false for nan
+            bool c = l[o] >= fs.st[o].m + lt;                             // >=: lt may be absorbed when |lnl| is huge; false for nan
+            if (TAIL) c = c && (j < M);      // a pad lane that never saw a real model has m = -inf and would pass (-inf >= -inf):
+                                             // only real models may be recorded, the list holds exactly M entries
             const unsigned long long mask = __ballot(c);
             if (mask) {                                                   // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),

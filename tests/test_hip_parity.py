@@ -393,3 +393,33 @@ def test_object_per_lane_path_matches(kw, monkeypatch):
     close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:60].copy(), Xe[:60].copy(), Xm[:60].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p1[:60], rp, rtol=1e-8, atol=1e-14); close(lm1[:60], rlm); close(le1[:60], rle)
+
+
+@pytest.mark.parametrize('N,M', [(1, 1), (3, 2), (5, 63), (2, 64), (4, 256), (3, 257), (0, 10)])
+def test_tiny_and_boundary_shapes(N, M):
+    """one object / one model, model counts around the wave (64) and tile (256) sizes, and an
+    empty object set -- fused, planes and predict routes."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(1000 + 7 * N + M)
+    B = 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.3 * rs.randn(N, B) if N else np.zeros((0, B))
+    Xe = np.full((N, B), 0.3); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    for kw in ({}, {'free_scale': True, 'ignore_model_err': True}, {'free_scale': True}):
+        bf = BruteForce(Y, Ye, Ym)
+        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                     return_gof=True, verbose=False, save_fits=False)
+        assert p.shape == (N, d.Ngrid) and lm.shape == (N,) and le.shape == (N,)
+        if N == 0:
+            continue
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+        ok = np.isfinite(rle)                 # M == 1 with the free scale: chi2 == 0 exactly -> -inf / nan rows
+        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(lm[ok], rlm[ok]); close(le[ok], rle[ok])
+        assert np.isnan(p[~ok]).all() == np.isnan(rp[~ok]).all()
+        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
+        rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
+        fin = np.isfinite(rf['lnlike'])
+        close(bf.fit_lnlike[fin], rf['lnlike'][fin], rtol=1e-8, atol=1e-8)
+        close(bf.predict(z, ze, label_dict=d, verbose=False)[ok], rp[ok], rtol=1e-8, atol=1e-14)
