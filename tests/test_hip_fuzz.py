@@ -120,3 +120,32 @@ def test_random_knn_configuration(seed):
     np.testing.assert_allclose(le[ok], rle[ok], rtol=1e-9, atol=1e-9)
     fin = np.isfinite(rlnp) & same[:, None]
     np.testing.assert_allclose(nn.fit_lnprob[fin], rlnp[fin], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_configuration_full_chip_geometries(seed):
+    """enough objects (>= 64 per CU) for the 4x8 / 2x16 launch geometries, model counts off the
+    tile size; the oracle checks a sample of objects (objects are independent)."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(7000 + seed)
+    N = 16384 + int(rs.randint(1, 700))
+    M = int(rs.choice([300, 1000, 2049, 511]))
+    B = 5 if seed % 3 else int(rs.choice([4, 7]))
+    kw = [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}, {'dim_prior': False}][seed % 4]
+    sig = rs.uniform(0.2, 2.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .6, size=(M, B)); Ye = Y * rs.uniform(0.01, 0.08, size=(M, B))
+    Ym = np.ones((M, B)); Xm = np.ones((N, B))
+    if seed % 2:
+        Xm[rs.rand(N, B) < 0.05] = 0
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .3, N)[:, None] + sig * rs.randn(N, B); Xe = np.tile(sig, (N, 1))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, verbose=False, save_fits=False)
+    pick = np.concatenate([[0, 1, N - 1, N - 2], rs.choice(N, 40, replace=False)])
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    ok = np.isfinite(rp).all(axis=1)
+    np.testing.assert_allclose(p[pick][ok], rp[ok], rtol=2e-7, atol=1e-13)
+    np.testing.assert_allclose(lm[pick][ok], rlm[ok], rtol=1e-9); np.testing.assert_allclose(le[pick][ok], rle[ok], rtol=1e-9)
+    fin = np.isfinite(p).all(axis=1)
+    assert fin.mean() > 0.99 and np.abs(p[fin].sum(axis=1) - 1).max() < 1e-9
