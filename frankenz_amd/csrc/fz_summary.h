@@ -260,6 +260,33 @@ static __global__ __launch_bounds__(256) void k_summarize(const double* __restri
     }
 }
 
+// ---- pdfs_resample (pdf.py:855-896): numpy.interp of each row onto a new grid ----------------
+static __global__ __launch_bounds__(256) void k_resample(const double* __restrict__ pdfs, int64_t N, int G, const double* __restrict__ og,
+                                                         int Gn, const double* __restrict__ ng, double left, double right,
+                                                         int renormalize, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const double* p = pdfs + i * G;
+    double* o = out + i * Gn;
+    auto OG = [&](int k) { return og[k]; };
+    auto PV = [&](int k) { return p[k]; };
+    double s = 0.0;
+    for (int k = lane; k < Gn; k += 64) {
+        const double x = ng[k];
+        double v;
+        if (x != x) v = x;
+        else if (x < og[0]) v = left;                     // np.interp(left=..., right=...)
+        else if (x > og[G - 1]) v = right;
+        else v = interp1(x, OG, PV, G);
+        o[k] = v; s += v;
+    }
+    if (renormalize) {
+        s = wsum(s);
+        for (int k = lane; k < Gn; k += 64) o[k] = o[k] / s;
+    }
+}
+
 // ---- population overlap (samplers.py:66-76): one wave per object ------------------------------
 static __global__ __launch_bounds__(256) void k_overlap(const double* __restrict__ pdfs, int64_t N, int G,
                                                         const double* __restrict__ nz, int pi, int pj, double step,

@@ -192,6 +192,11 @@ class Engine(object):
         check(self.lib.fz_pdfs_summarize(self.h, ptr(pdfs), n, len(pgrid), ptr(pgrid), int(bool(renormalize)),
                                          ptr(urand), ptr(loss), ptr(widths), float(wscale), ptr(stats)))
 
+    def pdfs_resample(self, pdfs, old_grid, new_grid, left, right, renormalize, out, n=None):
+        n = len(pdfs) if n is None else n
+        check(self.lib.fz_pdfs_resample(self.h, ptr(pdfs), n, len(old_grid), ptr(old_grid), len(new_grid), ptr(new_grid),
+                                        float(left), float(right), int(bool(renormalize)), ptr(out)))
+
     def overlap_nz(self, pdfs, nz, pair, step, overlap, n=None):
         n = len(pdfs) if n is None else n
         out = np.zeros(1)

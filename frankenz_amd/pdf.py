@@ -17,7 +17,7 @@ import numpy as np
 from .engine import HostObjects, get_engine, kde_opts, like_opts
 
 __all__ = ["loglike", "logprob", "logprob_prior", "gaussian", "gauss_kde", "gauss_kde_dict",
-           "magnitude", "luptitude", "PDFDict", "pdfs_summarize"]
+           "magnitude", "luptitude", "PDFDict", "pdfs_summarize", "pdfs_resample"]
 
 
 def _ndim_dtype(data_mask, models_mask):
@@ -270,3 +270,15 @@ def pdfs_summarize(pdfs, pgrid, renormalize=True, rstate=None, pkern='lorentz', 
     s = stats
     return ((s[0], s[1], s[2], s[3]), (s[4], s[5], s[6], s[7]), (s[8], s[9], s[10], s[11]),
             (s[12], s[13], s[14], s[15]), (s[16], s[17], s[18], s[19]), s[20])
+
+
+def pdfs_resample(pdfs, old_grid, new_grid, renormalize=True, left=0., right=0., device=None):
+    """Resample PDFs onto a new grid (pdf.py:855-896: ``numpy.interp`` per row, then an
+    optional renormalisation to unit sum)."""
+    og = np.ascontiguousarray(old_grid, dtype=np.float64)
+    ng = np.ascontiguousarray(new_grid, dtype=np.float64)
+    if isinstance(pdfs, np.ndarray) or not hasattr(pdfs, "data_ptr"):
+        pdfs = np.ascontiguousarray(pdfs, dtype=np.float64)
+    out = np.empty((len(pdfs), len(ng)))
+    get_engine(device).pdfs_resample(pdfs, og, ng, left, right, renormalize, out, n=len(pdfs))
+    return out

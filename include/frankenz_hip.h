@@ -188,6 +188,12 @@ int  fz_knn_predict_logwt(fz_ctx* ctx, const double* logwt, const int64_t* neigh
 int  fz_pdfs_summarize(fz_ctx* ctx, double* pdfs, int64_t N, int64_t G, const double* pgrid,
                        int32_t renormalize, const double* urand, const double* loss,
                        const double* widths, double wconf_scale, double* stats);
+/* pdf.pdfs_resample (pdf.py:855-896): numpy.interp of every row of pdfs (N,G) from
+ * old_grid onto new_grid (Gn points), `left` / `right` beyond the old grid's ends,
+ * optional renormalisation to unit sum; out is (N,Gn). */
+int  fz_pdfs_resample(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const double* old_grid,
+                      int64_t Gn, const double* new_grid, double left, double right,
+                      int32_t renormalize, double* out);
 /* samplers.loglike_nz (samplers.py:23-86) for finite non-negative nz: overlap (N) =
  * pdfs @ nz + pair_step * (pdfs[:,i] - pdfs[:,j]) (pair_i < 0: no pair), lnlike =
  * sum(log(overlap)). */

@@ -476,6 +476,9 @@ def g10():
     work = pdfs.copy()
     res = rpdf.pdfs_summarize(work, g, renormalize=False, rstate=np.random.RandomState(10))
     out['noren_stats'] = np.array([a for grp in res[:5] for a in grp] + [res[5]])
+    out['new_grid'] = np.concatenate([[-0.5, -0.01], np.linspace(0.0, 7.3, 211), [3.0, 3.0]])[np.argsort(np.concatenate([[-0.5, -0.01], np.linspace(0.0, 7.3, 211), [3.0, 3.0]]), kind='stable')]
+    out['resampled'] = rpdf.pdfs_resample(pdfs.copy(), g, out['new_grid'])
+    out['resampled_lr'] = rpdf.pdfs_resample(pdfs.copy(), g, out['new_grid'], renormalize=False, left=-1., right=2.)
     # population overlap likelihood
     norm = pdfs / pdfs.sum(axis=1)[:, None]
     nz = norm.sum(axis=0) / norm.sum()

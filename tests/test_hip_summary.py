@@ -87,3 +87,12 @@ def test_loglike_nz_golden_and_device_stack():
     nz = big.sum(axis=0) / big.sum()
     ll = loglike_nz(nz, DevArray(big))
     np.testing.assert_allclose(ll, fo.loglike_nz(nz, big)[0], rtol=1e-13)
+
+
+def test_pdfs_resample_golden():
+    from frankenz_amd.pdf import pdfs_resample
+    g = load_golden('g10_summarize')
+    np.testing.assert_allclose(pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid']), g['resampled'], rtol=1e-13, atol=0,
+                               equal_nan=True)
+    np.testing.assert_allclose(pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid'], renormalize=False, left=-1., right=2.),
+                               g['resampled_lr'], rtol=1e-14, atol=0, equal_nan=True)

@@ -305,3 +305,9 @@ def test_g10_loglike_nz():
     ll, ov = fo.loglike_nz(g['nz'], norm, (120, 300), 1e-4)
     eq(ll, g['nz_pair_lnlike']); eq(ov, g['nz_pair_overlap'])
     assert fo.loglike_nz(-g['nz'], norm)[0] == -np.inf
+
+
+def test_g10_pdfs_resample():
+    g = load_golden('g10_summarize')
+    eq(fo.pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid']), g['resampled'])
+    eq(fo.pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid'], renormalize=False, left=-1., right=2.), g['resampled_lr'])
