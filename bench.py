@@ -123,6 +123,10 @@ def main():
     ap.add_argument("--prior", type=int, default=0,
                     help="P > 0: add an ln-prior table of P rows (one row index per object) to the "
                          "fused path (the device form of a custom lprob_func, SURVEY 8f-1)")
+    ap.add_argument("--model-err", choices=["const", "varying"], default="const",
+                    help="const: ye = sigma_b for every model (SURVEY 8d configs; the library folds band-constant model "
+                         "errors into the object variances).  varying: ye = sigma_b * U(0.5, 1.5) per model and band "
+                         "(the general mode A kernels)")
     ap.add_argument("--wt-thresh", type=float, default=1e-3, help="kde_kwargs wt_thresh (reference default 1e-3)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -134,6 +138,8 @@ def main():
     kw = MODES[args.mode]
     N, M = args.nobj, args.nmodel
     Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank)
+    if args.model_err == "varying":
+        Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
     cpu1 = cpuall = None
     if world == 1 and not args.no_cpu and args.workload == "fit_predict" and not args.prior:
@@ -314,7 +320,10 @@ def main():
                                    "dict KDE on 701-pt grid" % (N, M, args.mode),
                        "n_obj_per_gpu": N, "n_model": M, "n_band": 5, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
-                       "mask_frac": args.mask_frac, "prior_rows": args.prior},
+                       "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err},
+            "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "
+                     "and mode A runs on the mode-Ai kernels; --model-err varying times the general mode A kernels"
+                     if (args.model_err == "const" and args.mode in ("A", "An")) else None),
             "pdfs_per_s": float(world) * N * args.steps / dt,
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in

@@ -69,7 +69,8 @@ extern "C" int fz_set_workspace_limit(fz_ctx* c, int64_t bytes) {
 // models  (BruteForce.__init__, bruteforce.py:36-64)
 // ---------------------------------------------------------------------------
 // flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1,
-// bit2 = some value is outside the range the reciprocal-based fast arithmetic accepts
+// bit2 = some value is outside the range the reciprocal-based fast arithmetic accepts,
+// bit3 = the model errors of some band differ between models
 __global__ void k_prep_models(const double* y, const double* ye, const double* ym, int64_t M, int64_t Mp,
                               int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags,
                               double* rec0, int rw0, double* rec1, int rw1) {
@@ -82,6 +83,7 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
             vy = y[j * B + b];
             const double e = ye[j * B + b];
             ve2 = e * e; ve = e;
+            if (!(e == ye[b])) fl |= 8;                        // vs model 0 (nan counts as different)
             const double mk = ym[j * B + b];
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
@@ -130,6 +132,17 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     c->M = M; c->Mp = Mp; c->B = B; c->BT = BT;
     c->models_masked = (fl & 1) || (BT != B);
     c->models_wild = (fl & 4) != 0;
+    // band-constant model errors (zeros for a template grid, a common floor, the SURVEY 8d
+    // configurations): xe^2 + ye^2 does not depend on the model, so it is formed once per object
+    // and mode A runs on the kernels of mode Ai (see obj_vmode); FZ_NO_ERRCONST=1 disables this
+    c->models_err_const = !(fl & 8) && !getenv("FZ_NO_ERRCONST");
+    {
+        std::vector<double> e0(B), e2(BT, 0.0);
+        FZCHK(copy_out(c, e0.data(), c->d_rxe.p, (size_t)B * 8));
+        for (int b = 0; b < B; ++b) e2[b] = e0[b] * e0[b];
+        FZCHK(c->d_ye2c.ensure((size_t)BT * 8));
+        FZCHK(copy_in(c, c->d_ye2c.p, e2.data(), (size_t)BT * 8));
+    }
     // gammaln(a) + a ln2 tables: a = n/2 (pdf.py:91-93) and a = (n-1)/2 (pdf.py:227-229)
     std::vector<double> ta(BT + 1), tb(BT + 1);
     for (int n = 0; n <= BT; ++n) {
@@ -269,12 +282,13 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
 // ---------------------------------------------------------------------------
 // objects: clean (pdf.py:309-311) + per-chunk derived arrays
 // ---------------------------------------------------------------------------
-// vmode 0: v = xe^2 (modes A, C) ; 1: v = 1/xe^2 (modes Ai, B)
+// vmode 0: v = xe^2 (modes A, C) ; 1: v = 1/xe^2 (modes Ai, B) ; 2: v = 1/(xe^2 + ye2c[b]) (mode A with
+// band-constant model errors, evaluated by the mode Ai kernels; slv = sum log(xe^2 + ye2c))
 // flags: bit0 some data mask is 0 after cleaning, bit1 some mask non-binary,
 // bit2 some value outside the fast arithmetic's range
 __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int B, int BT, int vmode,
                                int derive, double* ox, double* ov, uint32_t* bits, double* slv,
-                               int* flags) {
+                               int* flags, const double* __restrict__ ye2c) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     uint32_t bt = 0; int fl = 0; double sl = 0.0;
@@ -286,7 +300,7 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
             if (!clean) { f = 0.0; e = 1.0; mk = 0.0; x[i * B + b] = f; xe[i * B + b] = e; xm[i * B + b] = mk; }
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
-            const double e2 = e * e;
+            const double e2 = (vmode == 2) ? e * e + ye2c[b] : e * e;       // pdf.py:77 tot_var
             if (!(e2 > 1e-30 && e2 < 1e30) || !(fabs(f) < 1e30)) fl |= 4;
             sl += log(e2);
             fx = f;
@@ -324,7 +338,7 @@ static int prep_chunk(fz_ctx* c, double* x, double* xe, double* xm, int64_t i0, 
         Timer t(c, &c->tm.ms_other, &c->tm.n_other);
         hipLaunchKernelGGL(k_prep_objects, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ch.x, ch.xe, ch.xm,
                            n, B, BT, vmode, derive ? 1 : 0, c->d_ox.as<double>(), c->d_ov.as<double>(),
-                           c->d_obits.as<uint32_t>(), c->d_oslv.as<double>(), c->d_flags.as<int>());
+                           c->d_obits.as<uint32_t>(), c->d_oslv.as<double>(), c->d_flags.as<int>(), c->d_ye2c.as<double>());
     }
     HIPCHK(hipGetLastError());
     FZCHK(copy_out(c, &flags, c->d_flags.p, sizeof(int)));
@@ -527,7 +541,7 @@ extern "C" int fz_fit_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_
     if (!c->M) return fail(-1, "fz_fit: models have not been uploaded");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    const int mode = like_mode(o);
+    const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M;
     PriorBind pb; PriorGuard guard{c};
     FZCHK(prior_begin(c, pr, N, M, pb));
@@ -545,7 +559,7 @@ extern "C" int fz_fit_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
-        FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
+        FZCHK(prep_chunk(c, x, xe, xm, i0, n, obj_vmode(c, like_mode(o)), true, ch, fl));
         FZCHK(prior_chunk(c, pb, i0, n, M));
         const int var = pick_var(c, fl);
         const bool masked = var != VAR_FAST;
@@ -588,7 +602,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     FZCHK(check_kde_opts(ko));
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    const int mode = like_mode(o);
+    const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M, G = c->G;
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
     const bool pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
@@ -601,7 +615,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
         const int64_t n = std::min(nc, N - i0);
         ObjChunk ch; int fl = 0;
-        FZCHK(prep_chunk(c, x, xe, xm, i0, n, (mode == 1 || mode == 2) ? 1 : 0, true, ch, fl));
+        FZCHK(prep_chunk(c, x, xe, xm, i0, n, obj_vmode(c, like_mode(o)), true, ch, fl));
         FZCHK(prior_chunk(c, pb, i0, n, M));
         const int var = pick_var(c, fl);
         const bool masked = var != VAR_FAST;

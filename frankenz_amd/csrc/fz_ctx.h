@@ -58,8 +58,8 @@ struct fz_ctx {
 
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
-    bool models_masked = false, models_wild = false;
-    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1;
+    bool models_masked = false, models_wild = false, models_err_const = false;
+    DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1, d_ye2c;
     // kde dictionary (PDFDict)
     int64_t G = 0, D = 0;
     std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
@@ -84,7 +84,7 @@ struct fz_ctx {
     DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm;
 
     std::vector<DevBuf*> all_bufs() {
-        std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
+        std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
                                   &d_cls, &d_norm, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_kv, &d_olstats, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
@@ -151,6 +151,14 @@ inline fz::LikeParams like_params(fz_ctx* c, int mode, int dim_prior) {
 inline int like_mode(const fz_like_opts* o) {      // 0 A, 1 Ai, 2 B, 3 C
     if (!o->free_scale) return o->ignore_model_err ? 1 : 0;
     return o->ignore_model_err ? 2 : 3;
+}
+// Mode A (fixed scale, model errors kept) with band-constant model errors is mode Ai on the
+// variances xe^2 + ye^2[b], which then belong to the object: same chi2, N_dim and ln-like
+// (pdf.py:76-98) to the rounding of one reciprocal, at the cost of the cheaper kernel.
+inline int eff_mode(const fz_ctx* c, int mode) { return (mode == 0 && c->models_err_const) ? 1 : mode; }
+inline int obj_vmode(const fz_ctx* c, int mode) {      // what k_prep_objects derives (see there)
+    if (mode == 0) return c->models_err_const ? 2 : 0;
+    return (mode == 1 || mode == 2) ? 1 : 0;
 }
 // arithmetic variant of a chunk: see VAR_* in fz_device.h
 inline int pick_var(fz_ctx* c, int obj_flags) {

@@ -423,3 +423,39 @@ def test_tiny_and_boundary_shapes(N, M):
         fin = np.isfinite(rf['lnlike'])
         close(bf.fit_lnlike[fin], rf['lnlike'][fin], rtol=1e-8, atol=1e-8)
         close(bf.predict(z, ze, label_dict=d, verbose=False)[ok], rp[ok], rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'dim_prior': False}])
+@pytest.mark.parametrize('errs', ['band_constants', 'zeros', 'one_band_inf'])
+def test_band_constant_model_errors_take_the_hoisted_path(kw, errs, monkeypatch):
+    """model errors that are the same for every model (per band) are folded into the object's
+    variances and mode A runs on the mode Ai kernels: same results as the general kernels
+    (FZ_NO_ERRCONST=1) and as the oracle; masks and the unmasked log-variance sum included."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(88)
+    M, N, B = 900, 70, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3
+    Ye = np.tile({'band_constants': np.array([0.3, 0.1, 0.25, 0.6, 1.1]), 'zeros': np.zeros(B),
+                  'one_band_inf': np.array([0.3, np.inf, 0.25, 0.6, 1.1])}[errs], (M, 1))
+    Ym = np.ones((M, B)); Ym[rs.rand(M, B) < 0.05] = 0
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    Xm[rs.rand(N, B) < 0.1] = 0; X[3, 2] = np.nan
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+
+    def run():
+        bf = BruteForce(Y, Ye, Ym)
+        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True,
+                                     verbose=False, save_fits=True)
+        return p, lm, le, bf.fit_lnlike, bf.fit_chi2, bf.fit_Ndim
+    a = run()
+    monkeypatch.setenv('FZ_NO_ERRCONST', '1')
+    b = run()
+    monkeypatch.delenv('FZ_NO_ERRCONST')
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-12, equal_nan=True)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
+    close(a[0], rp, rtol=1e-8, atol=1e-13); close(a[1], rlm); close(a[2], rle)
+    close(a[3], rf['lnlike'], rtol=1e-9, atol=1e-9); close(a[4], rf['chi2'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(a[5], rf['Ndim'])
