@@ -694,14 +694,31 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                     for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
                     const double thr = wt_thresh * exp_neg(mx - le, tb);
                     const Cand* cb = buf + (size_t)o * cap;
-                    for (int c0 = 0; c0 < n; c0 += 64) {
-                        const int k = c0 + lane;
-                        const bool in = k < n;
-                        const Cand e = cb[in ? k : 0];
-                        double l = e.lnl;
-                        if constexpr (WM) { l = in ? src.lnl_of_chi2(e.lnl) : -INFINITY; lbest = fmax(lbest, l); }
-                        const double w = exp_neg(l - le, tb);
-                        kde_scatter(kv, row, in && (w > thr), w, e.j, lane);
+                    // A wave walks its object's list alone, so each trip is two dependent memory
+                    // round trips (the entries, then the labels of the selected ones): four
+                    // 64-entry blocks are kept in flight per trip to overlap them.
+                    constexpr int U = 4;
+                    for (int c0 = 0; c0 < n; c0 += 64 * U) {
+                        Cand e[U]; bool in[U], sel[U]; double w[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = cb[in[u] ? k : 0]; }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            double l = e[u].lnl;
+                            if constexpr (WM) { l = in[u] ? src.lnl_of_chi2(e[u].lnl) : -INFINITY; lbest = fmax(lbest, l); }
+                            w[u] = exp_neg(l - le, tb);
+                            sel[u] = in[u] && (w[u] > thr);
+                        }
+                        if (kv.kmode == KDE_HIST) {
+                            int p[U]; double nr[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[p[u] + kv.w0], w[u] / nr[u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], e[u].j, lane);
+                        }
                     }
                 }
                 if (WM) {
