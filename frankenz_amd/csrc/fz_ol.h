@@ -18,11 +18,12 @@
 // Built for the mask-free weight-space likelihoods (SRC::WPOW == 3, dim_prior on).
 //
 // STATUS: alternative path, selected with FZ_OL=1 (parity-tested, not the default).  Measured on
-// MI355X, 262144 x 1e5 x 5, mode A (profiles/README.md, r1_v4): k_ol 61.5 ms = 4.3e11 evals/s
-// against 82 ms for the model loop of k_fused -- but on the SURVEY 8d data 7 % of all pairs pass
-// the weight threshold (7 242 of 7 255 flagged models per object are finally stacked), and
-// handing that many pairs to the PDF stage through bits + recomputation costs 45 ms against
-// 23 ms for k_fused's in-kernel candidate lists, so the totals tie at ~105 ms.  The path wins
+// MI355X, 262144 x 1e5 x 5 (profiles/README.md): the model loop runs at 5.7e11 evals/s with
+// band-constant model errors (46 ms; k_fused's loop: 61 ms) and 4.5e11 with per-model errors
+// (58 ms; k_fused: 78 ms) -- but on the SURVEY 8d data 7 % of all pairs pass the weight threshold
+// (7 242 of 7 255 flagged models per object are finally stacked), and handing that many pairs to
+// the PDF stage through bits + recomputation costs 35-44 ms against 13 ms for k_fused's
+// in-kernel candidate lists, so the totals are 82 vs 74 ms and 102 vs 92 ms.  The path wins
 // only when posteriors are narrow (few pairs above the threshold).
 #pragma once
 #include "fz_kernels.h"
@@ -125,12 +126,12 @@ __global__ __launch_bounds__(256) void k_ol(SRC src_, int64_t N, int M, double w
 
 // PDF stage: a block of NWV waves takes NWV consecutive objects (one per wave).  The objects'
 // candidate words are fetched by the whole block, FZ_OL_TILE word rows at a time, as 4*NWV-byte
-// row segments and parked transposed in LDS; each wave then expands its own words, 1024 models
-// at a time, into a list of model indices, recomputes those candidates' likelihoods 64 at a
+// row segments and parked transposed in LDS; each wave then expands its own words, 4096 models
+// at a time, into a list of model indices, recomputes those candidates' likelihoods 256 at a
 // time (a lane per candidate), applies the exact threshold (pdf.py:510 / 591) against the final
 // max and evidence, and stacks the kernels.
 #define FZ_OL_TILE 256          // word rows per cooperative fetch
-#define FZ_OL_SEG 1024          // models expanded per list
+#define FZ_OL_SEG 4096          // models expanded per list (128 words: two per lane)
 template <class SRC, int NWV>
 __global__ __launch_bounds__(NWV * 64) void k_ol_pdf(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
                                                      double wt_thresh, int normalize, const uint32_t* __restrict__ mask,
@@ -172,29 +173,50 @@ __global__ __launch_bounds__(NWV * 64) void k_ol_pdf(SRC src_, const KdeView* __
         }
         __syncthreads();
         if (!ok) continue;
-        for (int sub = 0; sub < FZ_OL_TILE; sub += 32) {
+        for (int sub = 0; sub < FZ_OL_TILE; sub += FZ_OL_SEG / 32) {
             if (wt0 + sub >= W) break;
-            uint32_t word = (lane < 32) ? tile[wave * FZ_OL_TILE + sub + lane] : 0u;
-            if (__ballot(word != 0u) == 0ull) continue;
-            const int pc = __popc(word);
+            // lane l expands words 2l and 2l+1 of the segment (consecutive models stay consecutive in the list)
+            uint32_t wa = tile[wave * FZ_OL_TILE + sub + 2 * lane], wb = tile[wave * FZ_OL_TILE + sub + 2 * lane + 1];
+            if (__ballot((wa | wb) != 0u) == 0ull) continue;
+            const int pc = __popc(wa) + __popc(wb);
             int inc = pc;
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
-            const int total = __shfl(inc, 31, 64);
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+            const int total = __shfl(inc, 63, 64);
             int pos = inc - pc;
-            while (word) { const int b = __ffs((int)word) - 1; list[pos++] = (unsigned short)(lane * 32 + b); word &= word - 1u; }
+            while (wa) { const int b = __ffs((int)wa) - 1; list[pos++] = (unsigned short)(lane * 64 + b); wa &= wa - 1u; }
+            while (wb) { const int b = __ffs((int)wb) - 1; list[pos++] = (unsigned short)(lane * 64 + 32 + b); wb &= wb - 1u; }
             const int jbase = (wt0 + sub) * 32;
-            for (int c0 = 0; c0 < total; c0 += 64) {
-                const int k = c0 + lane;
-                const bool in = k < total;
-                const int j = jbase + (int)list[in ? k : 0];
-                typename SRC::MR m;
-                src.load_model_rec16(j, m);                        // per-lane gather of the 80-B record
-                double l = src.lnl_of_chi2(src.chi2_of(ob, m));
-                l = in ? l : -INFINITY;
-                lbest = fmax(lbest, l);
-                const double w = exp_neg(l - le, tb);
-                kde_scatter(kv, row, in && (w > thr), w, j, lane);
+            // four 64-candidate blocks in flight per trip (record gathers, then label gathers)
+            constexpr int U = 4;
+            for (int c0 = 0; c0 < total; c0 += 64 * U) {
+                bool in[U], sel[U]; int jj[U]; double w[U];
+                typename SRC::MR m[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = c0 + u * 64 + lane;
+                    in[u] = k < total;
+                    jj[u] = jbase + (int)list[in[u] ? k : 0];
+                    src.load_model_rec16(jj[u], m[u]);             // per-lane gather of the 80-B record
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    double l = src.lnl_of_chi2(src.chi2_of(ob, m[u]));
+                    l = in[u] ? l : -INFINITY;
+                    lbest = fmax(lbest, l);
+                    w[u] = exp_neg(l - le, tb);
+                    sel[u] = in[u] && (w[u] > thr);
+                }
+                if (kv.kmode == KDE_HIST) {
+                    int p[U]; double nr[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const int j = sel[u] ? jj[u] : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[p[u] + kv.w0], w[u] / nr[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], jj[u], lane);
+                }
             }
         }
     }
