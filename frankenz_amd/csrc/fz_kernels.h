@@ -46,7 +46,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr bool HAS_PRIOR = PRI;
     static constexpr int NB = BT;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
-    static constexpr bool PREF_2x16 = (MODE == 2 && VAR == VAR_FAST) || (MODE != 2 && VAR == VAR_MASKED);
+    static constexpr bool PREF_2x16 = (MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST);
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {

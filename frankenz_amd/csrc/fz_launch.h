@@ -181,9 +181,9 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             else r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
             int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
-            // measured best geometry per kernel body (profiles/README.md, r1_v4 sweep): the
-            // weight-space body, unmasked mode B and masked modes A / Ai fit 128 VGPRs and like
-            // 16 waves x 2 objects; the rest want the 256-VGPR budget of 8 waves x 4 objects
+            // measured best geometry per kernel body (profiles/README.md, r1_v5 sweep): 16 waves x
+            // 2 objects (128 VGPRs) for the weight-space body and every ln-space body except
+            // unmasked mode A and masked mode B, which want the 256-VGPR budget of 8 waves x 4
             if (tw == 4 && (fz_use_wspace(src) || SRC::PREF_2x16)) { tw = 2; nw = 16; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
