@@ -176,9 +176,10 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             // wide records (17-32 bands): one object per wave keeps the kernel inside the register file
             r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else if constexpr (SRC::HAS_PRIOR) {
-            // ln-prior rows are streamed from HBM beside the LDS model tiles: two geometries only
-            if (n >= (int64_t)c->cu_count * 64) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            else r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            // ln-prior rows are streamed from HBM beside the LDS model tiles: two geometries per body
+            if (n < (int64_t)c->cu_count * 64) r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else if constexpr (SRC::PREF_2x16) r = fz_launch_fused_tw<SRC, 2, 16>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
             int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
             // measured best geometry per kernel body (profiles/README.md, r1_v5 sweep): 16 waves x
