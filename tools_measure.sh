@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
 python3 bench.py > $O/m_bench_fit_predict_modeA.json 2> $O/m_bench_fit_predict_modeA.err
+python3 bench.py --model-err varying --no-cpu > $O/m_bench_fit_predict_modeA_varying_model_errors.json 2>/dev/null
 python3 bench.py --mode B --no-cpu > $O/m_bench_fit_predict_modeB.json 2>/dev/null
 python3 bench.py --mode Ai --no-cpu > $O/m_bench_fit_predict_modeAi.json 2>/dev/null
 python3 bench.py --mode A --mask-frac 0.02 --no-cpu > $O/m_bench_fit_predict_masked.json 2>/dev/null
