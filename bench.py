@@ -328,7 +328,9 @@ def main():
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in
                                    ("fused", "stats", "kde", "planes", "modec", "other")},
-            "roofline": {"bound": "valu_fp64", "kernel": "k_" + fam, "achieved": ach,
+            "roofline": {"bound": "mfma", "pipe": "valu_fp64 (the fp64 vector rate equals the dense fp64 MFMA peak on gfx950; "
+                                                   "the kernel is compute-bound on the vector ALU, see DESIGN.md 3.6)",
+                         "kernel": "k_" + fam, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_eval": flops_eval,
