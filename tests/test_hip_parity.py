@@ -459,3 +459,31 @@ def test_band_constant_model_errors_take_the_hoisted_path(kw, errs, monkeypatch)
     close(a[0], rp, rtol=1e-8, atol=1e-13); close(a[1], rlm); close(a[2], rle)
     close(a[3], rf['lnlike'], rtol=1e-9, atol=1e-9); close(a[4], rf['chi2'], rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(a[5], rf['Ndim'])
+
+
+@pytest.mark.parametrize('env', [{'FZ_FUSED_CFG': '4,8'}, {'FZ_FUSED_CFG': '2,8'}, {'FZ_FUSED_CFG': '2,16'},
+                                 {'FZ_FUSED_CFG': '1,4'}, {'FZ_NO_WSPACE': '1'}, {'FZ_CHUNK': '5000'},
+                                 {'FZ_NO_WSPACE': '1', 'FZ_FUSED_CFG': '2,16'}])
+def test_tuning_switches_do_not_change_results(env, monkeypatch):
+    """every launch geometry / kernel body / chunking reachable through the diagnostic
+    environment switches gives the same PDFs (summation order aside)."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(123)
+    M, N, B = 777, 16500, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = Y * rs.uniform(0.02, 0.08, size=(M, B)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    out = {}
+    for kw in ({}, {'free_scale': True, 'ignore_model_err': True}):
+        run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                        return_gof=True, save_fits=False, verbose=False)
+        p0, (lm0, le0) = run()
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p1, (lm1, le1) = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:30].copy(), Xe[:30].copy(), Xm[:30].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(p1[:30], rp, rtol=1e-8, atol=1e-14)
