@@ -40,18 +40,18 @@ using namespace fz;
 
 int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, double* lnl, double* chi2,
                           int64_t* ndim, double* scale, double* serr) {
-    constexpr int TO = 16;
     const int64_t M = c->M;
+    // objects per block: 256 when the grid still holds >= 4 blocks per CU (+11 % at 1e5 x 1e4), else 16
+    const bool big = ((n + 255) / 256) * ((M + 255) / 256) >= 4 * (int64_t)c->cu_count;
+    const int TO = big ? 256 : 16;
     dim3 grid((unsigned)((n + TO - 1) / TO), (unsigned)((M + 255) / 256));
     Timer t(c, &c->tm.ms_planes, &c->tm.n_planes);
 #define FZ_CALL_PLANES(BT_, MODE_, VAR_)                                                                  \
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
-    if (dim_prior)                                                                                         \
-        hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO, 1>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, \
-                           chi2, ndim, scale, serr);                                                       \
-    else                                                                                                   \
-        hipLaunchKernelGGL((k_planes<PhotSrc<BT_, MODE_, VAR_>, TO, 0>), grid, dim3(256), 0, c->stream, ph, n, M, lnl, \
-                           chi2, ndim, scale, serr);
+    using PH_ = PhotSrc<BT_, MODE_, VAR_>;                                                                \
+    auto kern = dim_prior ? (big ? k_planes<PH_, 256, 1> : k_planes<PH_, 16, 1>)                           \
+                          : (big ? k_planes<PH_, 256, 0> : k_planes<PH_, 16, 0>);                          \
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, ph, n, M, lnl, chi2, ndim, scale, serr);
     FZ_SWITCH(FZ_CALL_PLANES)
     HIPCHK(hipGetLastError());
     return 0;

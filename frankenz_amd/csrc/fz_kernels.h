@@ -139,7 +139,8 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
 };
 
 // ---- materialising fit ------------------------------------------------------
-// A thread owns one model (registers); the block walks TO objects, UNR at a time so that
+// A thread owns one model (registers); the block walks TO objects (16 for small problems, 256
+// when that still fills the chip: fewer model loads per plane element), UNR at a time so that
 // the independent evaluations interleave; rows of the (N,M) planes are written as
 // coalesced 512-B-per-wave stores.
 template <class PH, int TO, int DPT>
