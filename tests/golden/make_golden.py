@@ -489,6 +489,30 @@ def g10():
     save('g10_summarize', **out)
 
 
+def g11():
+    """_Network.populate_network (networks.py:176-356) with hand-set nodes: the node lists,
+    ln-weights, scales and per-model (lmap, levid) for both thresholding rules."""
+    from frankenz.networks import _Network
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(1111, 10, 90)
+    rs = np.random.RandomState(11)
+    nodes = Y[rs.choice(len(Y), 12, replace=False)] * rs.lognormal(0, 0.2, size=(12, 5))
+    out = dict(models=Y, models_err=Ye, models_mask=Ym, nodes=nodes)
+    for tag, kw in (('wt', dict(wt_thresh=1e-3)), ('cdf', dict(wt_thresh=None, cdf_thresh=0.05)),
+                    ('fixed', dict(wt_thresh=1e-2, track_scale=False,
+                                   lpnet_kwargs={'free_scale': False, 'ignore_model_err': True}))):
+        net = _Network(Y.copy(), Ye.copy(), Ym.copy())
+        net.nodes = nodes.copy(); net.NNODE = len(nodes)
+        net.populate_network(verbose=False, **kw)
+        out[tag + '_Nmatch'] = net.nodes_Nmatch
+        out[tag + '_lmap'], out[tag + '_levid'] = net.models_lmap, net.models_levid
+        out[tag + '_bmu_of_model'] = np.array([[j for j in range(len(nodes)) if i in net.nodes_bmus[j]][0] for i in range(len(Y))])
+        out[tag + '_idxs'] = np.concatenate([np.array(v, dtype='int') for v in net.nodes_idxs])
+        out[tag + '_logwts'] = np.concatenate([np.array(v, dtype='float') for v in net.nodes_logwts])
+        out[tag + '_scales'] = np.concatenate([np.array(v, dtype='float') for v in net.nodes_scales])
+        out[tag + '_scales_err'] = np.concatenate([np.array(v, dtype='float') for v in net.nodes_scales_err])
+    save('g11_network_map', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for nm in sys.argv[1:]:

@@ -96,3 +96,22 @@ def test_pdfs_resample_golden():
                                equal_nan=True)
     np.testing.assert_allclose(pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid'], renormalize=False, left=-1., right=2.),
                                g['resampled_lr'], rtol=1e-14, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize('tag,kw,lk', [('wt', dict(wt_thresh=1e-3), None), ('cdf', dict(wt_thresh=None, cdf_thresh=0.05), None),
+                                       ('fixed', dict(wt_thresh=1e-2, track_scale=False),
+                                        {'free_scale': False, 'ignore_model_err': True})])
+def test_g11_network_map_golden(tag, kw, lk):
+    """networks.populate_network: node likelihoods on the GPU, lists as the reference builds them."""
+    from frankenz_amd.networks import populate_network
+    g = load_golden('g11_network_map')
+    r = populate_network(g['nodes'], g['models'].copy(), g['models_err'].copy(), g['models_mask'].copy(), lpnet_kwargs=lk, **kw)
+    np.testing.assert_array_equal(r.nodes_Nmatch, g[tag + '_Nmatch'])
+    np.testing.assert_allclose(r.models_lmap, g[tag + '_lmap'], rtol=1e-10); np.testing.assert_allclose(r.models_levid, g[tag + '_levid'], rtol=1e-10)
+    np.testing.assert_array_equal(np.concatenate([np.array(v, dtype='int') for v in r.nodes_idxs]), g[tag + '_idxs'])
+    cat = lambda L: np.concatenate([np.array(v, dtype='float') for v in L])
+    np.testing.assert_allclose(cat(r.nodes_logwts), g[tag + '_logwts'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cat(r.nodes_scales), g[tag + '_scales'], rtol=1e-10)
+    np.testing.assert_allclose(cat(r.nodes_scales_err), g[tag + '_scales_err'], rtol=1e-10)
+    bmu = np.array([[j for j in range(len(g['nodes'])) if i in r.nodes_bmus[j]][0] for i in range(len(g['models']))])
+    np.testing.assert_array_equal(bmu, g[tag + '_bmu_of_model'])

@@ -311,3 +311,22 @@ def test_g10_pdfs_resample():
     g = load_golden('g10_summarize')
     eq(fo.pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid']), g['resampled'])
     eq(fo.pdfs_resample(g['pdfs_in'].copy(), g['grid'], g['new_grid'], renormalize=False, left=-1., right=2.), g['resampled_lr'])
+
+
+NET_CASES = [('wt', dict(wt_thresh=1e-3), {}), ('cdf', dict(wt_thresh=None, cdf_thresh=0.05), {}),
+             ('fixed', dict(wt_thresh=1e-2, track_scale=False), {'free_scale': False, 'ignore_model_err': True})]
+
+
+@pytest.mark.parametrize('tag,kw,lk', NET_CASES)
+def test_g11_network_map(tag, kw, lk):
+    """_Network.populate_network (networks.py:244-354)."""
+    g = load_golden('g11_network_map')
+    r = fo.populate_network(g['nodes'], g['models'].copy(), g['models_err'].copy(), g['models_mask'].copy(), **kw, **lk)
+    np.testing.assert_array_equal(r['Nmatch'], g[tag + '_Nmatch'])
+    eq(r['lmap'], g[tag + '_lmap']); eq(r['levid'], g[tag + '_levid'])
+    np.testing.assert_array_equal(np.concatenate([np.array(v, dtype='int') for v in r['idxs']]), g[tag + '_idxs'])
+    eq(np.concatenate([np.array(v, dtype='float') for v in r['logwts']]), g[tag + '_logwts'])
+    eq(np.concatenate([np.array(v, dtype='float') for v in r['scales']]), g[tag + '_scales'])
+    eq(np.concatenate([np.array(v, dtype='float') for v in r['scales_err']]), g[tag + '_scales_err'])
+    bmu = np.array([[j for j in range(len(g['nodes'])) if i in r['bmus'][j]][0] for i in range(len(g['models']))])
+    np.testing.assert_array_equal(bmu, g[tag + '_bmu_of_model'])
