@@ -469,6 +469,16 @@ __global__ void k_prior_add(PriorView pv, const double* lnl, int64_t n, int64_t 
     if (lnprob) lnprob[k] = lnl[k] + p;
 }
 
+// objects of a chunk split by "every band observed" (all B mask bits set) or not
+__global__ void k_partition_masked(const uint32_t* __restrict__ bits, int64_t n, uint32_t full, int* __restrict__ fast,
+                                   int* __restrict__ masked, int* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((bits[i] & full) == full) fast[atomicAdd(&counts[0], 1)] = (int)i;
+    else masked[atomicAdd(&counts[1], 1)] = (int)i;
+}
+struct OmapGuard { fz_ctx* c; ~OmapGuard() { c->omap = nullptr; } };
+
 struct PriorBind {
     const fz_prior* pr = nullptr;
     int kind = 0;              // 0 none, 1 one row for all, 2 row i for object i, 3 rows[i]
@@ -641,7 +651,31 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
             if (c->prior.tab) FZCHK(prior_add(c, c->d_pl[0].as<double>(), n, M, nullptr, nullptr, nullptr, c->d_pl[0].as<double>()));
             FZCHK(run_cdf(c, n, (int)M, M, c->d_pl[0].as<double>(), nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
         } else {
-            FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));
+            // A chunk with some unobserved bands would run the masked kernels for every object.
+            // When the models themselves are unmasked, the (usually large) share of objects with
+            // every band observed keeps the mask-free kernels: the chunk is split in two launches.
+            bool done = false;
+            if (var == VAR_MASKED && !c->models_masked && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
+                FZCHK(c->d_omap.ensure((size_t)n * 8 + 64));
+                int* fast = c->d_omap.as<int>(); int* slow = fast + n; int* counts = slow + n;
+                HIPCHK(hipMemsetAsync(counts, 0, 8, c->stream));
+                hipLaunchKernelGGL(k_partition_masked, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->d_obits.as<uint32_t>(), n, (uint32_t)((1ull << c->B) - 1), fast, slow, counts);
+                HIPCHK(hipGetLastError());
+                int cnt[2] = {0, 0};
+                FZCHK(copy_out(c, cnt, counts, sizeof cnt));
+                if (cnt[0] >= 1024 && cnt[1] > 0) {
+                    OmapGuard og{c};
+                    c->omap = fast;
+                    const int r1 = run_fitpredict(c, mode, VAR_FAST, o->dim_prior, cnt[0], ko, d_lm, d_le, d_pdf);
+                    if (r1 < 0) return r1;
+                    c->omap = slow;
+                    const int r2 = (r1 == 0) ? run_fitpredict(c, mode, VAR_MASKED, o->dim_prior, cnt[1], ko, d_lm, d_le, d_pdf) : 2;
+                    if (r2 < 0) return r2;
+                    done = (r1 == 0 && r2 == 0);
+                }
+            }
+            if (!done) FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));
         }
         if (!pdf_dev) FZCHK(copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8));
         if (lmap && !lm_dev) FZCHK(copy_out(c, lmap + i0, d_lm, n * 8));

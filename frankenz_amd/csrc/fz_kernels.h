@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                                                     int M, double wt_thresh, int normalize,
                                                     Cand* __restrict__ cand, int64_t cap,
                                                     double* __restrict__ lmap, double* __restrict__ levid,
-                                                    double* __restrict__ pdfs) {
+                                                    double* __restrict__ pdfs, const int* __restrict__ omap) {
     // LDS (doubles): [2][TILE_DOUBLES] model tiles, aliased outside the model loop by
     // the [NW][acc_stride] PDF rows | [NW][TW][4] per-object results | log/exp tables
     // | [NW][TW][OBJ_DOUBLES] object rows.
@@ -594,7 +594,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         for (int o = 0; o < TW; ++o) {
             if (WM) { ws.ref[o] = -INFINITY; ws.kref[o] = -INFINITY; ws.s[o] = 0.0; ws.wmax[o] = 0.0; ws.cnt[o] = 0; }
             else { ms_init(fs.st[o]); fs.cnt[o] = 0; }
-            src.park_obj(i0 + o < N ? i0 + o : N - 1, objs + o * OD, lane);
+            // omap: the launch covers a subset of the chunk's objects (N of them), listed by index
+            const int64_t oslot = i0 + o < N ? i0 + o : N - 1;
+            src.park_obj(omap ? (int64_t)omap[oslot] : oslot, objs + o * OD, lane);
         }
         // tile 0 -> LDS.  Two staging forms, chosen per kernel body from measurements
         // (profiles/README.md): the ln-space bodies copy tiles with the LDS-DMA form of the load
@@ -684,8 +686,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             const KdeView kv = *kvp;
 #pragma unroll 1
             for (int o = 0; o < TW; ++o) {
-                const int64_t i = i0 + o;
-                if (i >= N) break;
+                if (i0 + o >= N) break;
+                const int64_t i = omap ? (int64_t)omap[i0 + o] : i0 + o;
                 const double lm = res[o * 4 + 0], le = res[o * 4 + 1], mx = res[o * 4 + 2];
                 const int n = __builtin_amdgcn_readfirstlane((int)res[o * 4 + 3]);
                 if (lane == 0 && !WM) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }

@@ -97,7 +97,8 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
-                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs);
+                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
+                       c->omap);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -167,7 +168,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int r = 1;
         if constexpr (SRC::WPOW == 3) {
-            if (fz_use_wspace(src) && getenv("FZ_OL")) {
+            if (fz_use_wspace(src) && getenv("FZ_OL") && !c->omap) {
                 r = fz_launch_ol<SRC, 2>(c, src, kv, n, M, ko, lmap, levid, pdfs);
                 if (r <= 0) return r;
             }
@@ -195,6 +196,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         }
         if (r <= 0) return r;
     }
+    if (c->omap) return 2;          // an object subset: only the fused kernel takes one; the caller redoes the whole chunk
     FZCHK(fz_launch_stats(c, src, n, M, 0, lmap, levid));
     return fz_launch_kde(c, src, n, M, 0, lmap, levid, ko, pdfs);
 }

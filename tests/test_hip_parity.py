@@ -487,3 +487,30 @@ def test_tuning_switches_do_not_change_results(env, monkeypatch):
         close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:30].copy(), Xe[:30].copy(), Xm[:30].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p1[:30], rp, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}, {'dim_prior': False}])
+def test_masked_and_unmasked_objects_split_across_kernels(kw, monkeypatch):
+    """a chunk that mixes fully observed objects with objects missing bands is run as two
+    launches (mask-free kernels + masked kernels): same results as the single masked launch
+    (FZ_NO_SPLIT=1) and as the oracle, for objects of both kinds."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(321)
+    M, N, B = 650, 9000, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = Y * rs.uniform(0.02, 0.08, size=(M, B)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    Xm[rs.rand(N, B) < 0.04] = 0
+    X[17, 1] = np.nan                              # cleaned in place -> becomes a masked object
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    p0, (lm0, le0) = run()
+    monkeypatch.setenv('FZ_NO_SPLIT', '1')
+    p1, (lm1, le1) = run()
+    monkeypatch.delenv('FZ_NO_SPLIT')
+    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-12); close(le0, le1, rtol=1e-12)
+    masked = np.where((Xm == 0).any(axis=1))[0][:25]; full = np.where((Xm == 1).all(axis=1))[0][:25]
+    pick = np.concatenate([masked, full, [17]])
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(p0[pick], rp, rtol=1e-8, atol=1e-14); close(lm0[pick], rlm); close(le0[pick], rle)
