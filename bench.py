@@ -40,16 +40,17 @@ MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True},
          "An": {"dim_prior": False}, "Bn": {"free_scale": True, "ignore_model_err": True, "dim_prior": False}}
 
 
-def make_problem(n_obj, n_model, seed):
-    """lognormal model fluxes, SDSS-depth noise."""
+def make_problem(n_obj, n_model, seed, B=5):
+    """lognormal model fluxes, SDSS-depth noise (B != 5, a side
+    experiment of --nband: the five SDSS depths repeated / truncated)."""
     rs = np.random.RandomState(seed)
-    B = 5
+    sig = np.resize(SDSS_SIGMA, B)
     Y = rs.lognormal(mean=1.0, sigma=1.0, size=(n_model, B))
-    Ye = np.tile(SDSS_SIGMA, (n_model, 1))
+    Ye = np.tile(sig, (n_model, 1))
     Ym = np.ones((n_model, B))
     pick = rs.randint(0, n_model, size=n_obj)
-    X = Y[pick] + SDSS_SIGMA * rs.standard_normal((n_obj, B))
-    Xe = np.tile(SDSS_SIGMA, (n_obj, 1))
+    X = Y[pick] + sig * rs.standard_normal((n_obj, B))
+    Xe = np.tile(sig, (n_obj, 1))
     Xm = np.ones((n_obj, B))
     z = rs.uniform(0.0, 6.0, n_model)
     ze = np.full(n_model, 0.05)
@@ -127,6 +128,7 @@ def main():
                     help="const: ye = sigma_b for every model (SURVEY 8d configs; the library folds band-constant model "
                          "errors into the object variances).  varying: ye = sigma_b * U(0.5, 1.5) per model and band "
                          "(the general mode A kernels)")
+    ap.add_argument("--nband", type=int, default=5, help="band count (headline: 5, the SDSS configuration)")
     ap.add_argument("--wt-thresh", type=float, default=1e-3, help="kde_kwargs wt_thresh (reference default 1e-3)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -137,7 +139,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     kw = MODES[args.mode]
     N, M = args.nobj, args.nmodel
-    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank)
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband)
     if args.model_err == "varying":
         Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
@@ -315,10 +317,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x 5 bands per GPU, "
+            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x %d bands per GPU, "
                                    "BruteForce.fit_predict(save_fits=False), likelihood mode %s, "
-                                   "dict KDE on 701-pt grid" % (N, M, args.mode),
-                       "n_obj_per_gpu": N, "n_model": M, "n_band": 5, "mode": args.mode,
+                                   "dict KDE on 701-pt grid" % (N, M, args.nband, args.mode),
+                       "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
                        "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err},
             "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "

@@ -181,7 +181,9 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
     int fz_knnsubset_bt##N(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const int64_t* idx, int W, \
                            const fz_kde_opts* ko, const fz::KnnOut* out, int* errflag);                   \
     int fz_knnquery_bt##N(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx, int pnorm);
+FZ_DECL_BT(4)
 FZ_DECL_BT(5)
+FZ_DECL_BT(6)
 FZ_DECL_BT(8)
 FZ_DECL_BT(16)
 FZ_DECL_BT(32)

@@ -1,7 +1,7 @@
 // Per-band-count instantiations of the photometric kernels.  Compiled once per
-// FZ_BT in {5, 8, 16} (separate translation units so they build in parallel).
+// FZ_BT in {4, 5, 6, 8, 16, 32} (separate translation units so they build in parallel).
 #ifndef FZ_BT
-#error "compile with -DFZ_BT=5|8|16|32"
+#error "compile with -DFZ_BT=4|5|6|8|16|32"
 #endif
 #include "fz_ctx.h"
 #include "fz_kernels.h"
@@ -14,9 +14,10 @@ using namespace fz;
 #define FZ_CAT(a, b) FZ_CAT_(a, b)
 #define FZ_NAME(base) FZ_CAT(base, FZ_BT)
 
-// VAR_FAST exists only when BT equals the real band count (B == 5): padded band
+// VAR_FAST exists only when BT equals the real band count (B in {4, 5, 6}): padded band
 // counts always carry mask bits.
-#if FZ_BT == 5
+#define FZ_EXACT_BT (FZ_BT == 4 || FZ_BT == 5 || FZ_BT == 6)
+#if FZ_EXACT_BT
 #define FZ_SWITCH_VAR(MODE_, CALL)                                         \
     switch (var) {                                                         \
         case 0: { CALL(FZ_BT, MODE_, 0); } break;                          \
@@ -112,7 +113,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
 
 int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr, const int64_t* nnb, int W) {
     SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
-#if FZ_BT == 5
+#if FZ_EXACT_BT
     return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o, sub) : run_modec<FZ_BT, true>(c, n, o, sub);
 #else
     (void)var;
@@ -124,7 +125,7 @@ int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, c
 // k-NN: brute-force search over the K feature sets and the subset likelihood/PDF
 // ---------------------------------------------------------------------------
 int FZ_NAME(fz_knnquery_bt)(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx, int pnorm) {
-    constexpr int TQ = (FZ_BT == 5) ? 4 : (FZ_BT == 8 ? 2 : 1);     // queries per wave (register budget)
+    constexpr int TQ = (FZ_BT <= 5) ? 4 : (FZ_BT <= 8 ? 2 : 1);     // queries per wave (register budget)
     const int64_t per = (int64_t)TQ * 4;
     dim3 grid((unsigned)((n + per - 1) / per), (unsigned)c->knn_K);
     Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);

@@ -45,6 +45,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr int WPOW = (VAR == VAR_FAST && !PRI) ? (MODE == 2 ? BT - 3 : BT - 2) : 0;
     static constexpr bool HAS_PRIOR = PRI;
     static constexpr int NB = BT;
+    static constexpr int LMODE = MODE;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
     static constexpr bool PREF_2x16 = (MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST);
     PriorView pv;                                 // read only when PRI
@@ -479,7 +480,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                                              WState<TW>& ws) {
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW;
-    static_assert(WP == 2 || WP == 3, "weight-space path is built for chi2^1 and chi2^(3/2)");
+    static_assert(WP >= 1 && WP <= 4, "weight-space path: chi2^(1/2) ... chi2^2 (4-6 exact bands)");
 #pragma unroll 1
     for (int s = 0; s < SRC::TILE / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
@@ -511,16 +512,19 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             const double e = exp_clamped(t[o], tb);
-            if (WP == 3) {
+            // chi2^(WP/2): integer powers by multiplication, the half by a Newton-refined v_rsq_f64
+            double pw = (WP >= 2) ? c2[o] : 1.0;                 // chi2^floor(WP/2) below
+            if (WP == 4) pw = c2[o] * c2[o];
+            if (WP & 1) {
                 const double cc = c2[o] + 1e-300;                // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
                 const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
                 double sq = cc * y;                              // ~sqrt(cc)
                 const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
                 sq = fma(sq, r, sq);
-                w[o] = (c2[o] * sq) * e;
-            } else {
-                w[o] = c2[o] * e;
+                if (WP == 1) pw = (c2[o] == 0.0) ? 0.0 : sq;     // sqrt(0 + 1e-300) must not leak a weight
+                else pw = c2[o] * sq;                            // WP == 3
             }
+            w[o] = pw * e;
             if (TAIL) w[o] = (j < M) ? w[o] : 0.0;
             ws.s[o] += w[o];
             ws.wmax[o] = vmax_raw(ws.wmax[o], w[o]);

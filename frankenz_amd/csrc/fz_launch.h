@@ -103,18 +103,21 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return 0;
 }
 
-// the weight-space kernel body is used for the chi2^(3/2) likelihoods (modes A / Ai, 5 bands,
-// dimensionality prior on); for mode B's chi2^1 the ln-space body measured as fast or faster at
-// every geometry, so it is not instantiated there (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+// the weight-space kernel body is used for the chi2^(k/2) likelihoods of the exact band counts
+// (4, 5, 6 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
+// the ln-space body measured as fast or faster for 5 and 6 bands, so the weight-space body is
+// instantiated there only for 4 bands (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+template <class SRC>
+constexpr bool fz_has_wspace() { return SRC::WPOW >= 1 && SRC::WPOW <= 4 && (SRC::LMODE != 2 || SRC::NB == 4); }
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
-    if constexpr (SRC::WPOW == 3) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE");
+    if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE");
     return false;
 }
 template <class SRC, int TW, int NW>
 int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    if constexpr (SRC::WPOW == 3) {
+    if constexpr (fz_has_wspace<SRC>()) {
         if (fz_use_wspace(src)) return fz_launch_fused_wm<SRC, TW, NW, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
     }
     return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
@@ -167,7 +170,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int r = 1;
-        if constexpr (SRC::WPOW == 3) {
+        if constexpr (SRC::WPOW == 3 && SRC::NB == 5) {
             if (fz_use_wspace(src) && getenv("FZ_OL") && !c->omap) {
                 r = fz_launch_ol<SRC, 2>(c, src, kv, n, M, ko, lmap, levid, pdfs);
                 if (r <= 0) return r;
