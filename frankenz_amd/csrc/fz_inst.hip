@@ -14,9 +14,9 @@ using namespace fz;
 #define FZ_CAT(a, b) FZ_CAT_(a, b)
 #define FZ_NAME(base) FZ_CAT(base, FZ_BT)
 
-// VAR_FAST exists only when BT equals the real band count (B in {4, 5, 6}): padded band
+// VAR_FAST exists only when BT can equal the real band count (B in {4, 5, 6, 8}): padded band
 // counts always carry mask bits.
-#define FZ_EXACT_BT (FZ_BT == 4 || FZ_BT == 5 || FZ_BT == 6)
+#define FZ_EXACT_BT (FZ_BT == 4 || FZ_BT == 5 || FZ_BT == 6 || FZ_BT == 8)
 #if FZ_EXACT_BT
 #define FZ_SWITCH_VAR(MODE_, CALL)                                         \
     switch (var) {                                                         \

@@ -47,7 +47,8 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr int NB = BT;
     static constexpr int LMODE = MODE;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
-    static constexpr bool PREF_2x16 = (MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST);
+    static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST));
+    static constexpr bool PREF_2x8 = (BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {
@@ -88,8 +89,10 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     // RW doubles) followed by the TILE mask words: a contiguous slice of the record
     // array, staged with plain 16-B-per-lane copies.  RW*8 is 16 mod 32 bytes, which
     // makes a wave's ds_read_b128 of 64 consecutive records bank-conflict free.
-    static constexpr int TILE = (BT > 16) ? 64 : 256;           // wide records: smaller tiles (LDS); 512 measured slower (staging registers)
     static constexpr int NVAL = BT + (MODE == 0 ? BT : 0);
+    // models per LDS tile: 256, fewer for wide records so that two tiles stay well inside the LDS
+    // (512 measured slower at 5 bands: staging registers)
+    static constexpr int TILE = (NVAL > 32) ? 64 : (NVAL > 16 ? 128 : 256);
     static constexpr int RW = NVAL + ((6 - NVAL % 4) % 4);          // smallest width >= NVAL that is 2 mod 4
     static_assert(RW >= NVAL && RW % 4 == 2, "record width must be 2 mod 4 doubles (16 mod 32 bytes)");
     static constexpr int TILE_DOUBLES = RW * TILE + (P::MASKED ? TILE / 2 : 0);
@@ -480,7 +483,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                                              WState<TW>& ws) {
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW;
-    static_assert(WP >= 1 && WP <= 4, "weight-space path: chi2^(1/2) ... chi2^2 (4-6 exact bands)");
+    static_assert(WP >= 1 && WP <= 6, "weight-space path: chi2^(1/2) ... chi2^3 (4-8 exact bands)");
 #pragma unroll 1
     for (int s = 0; s < SRC::TILE / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
@@ -513,8 +516,9 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
         for (int o = 0; o < TW; ++o) {
             const double e = exp_clamped(t[o], tb);
             // chi2^(WP/2): integer powers by multiplication, the half by a Newton-refined v_rsq_f64
-            double pw = (WP >= 2) ? c2[o] : 1.0;                 // chi2^floor(WP/2) below
-            if (WP == 4) pw = c2[o] * c2[o];
+            double pw = 1.0;                                     // chi2^floor(WP/2)
+#pragma unroll
+            for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? c2[o] : pw * c2[o];
             if (WP & 1) {
                 const double cc = c2[o] + 1e-300;                // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
                 const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
@@ -522,7 +526,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                 const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
                 sq = fma(sq, r, sq);
                 if (WP == 1) pw = (c2[o] == 0.0) ? 0.0 : sq;     // sqrt(0 + 1e-300) must not leak a weight
-                else pw = c2[o] * sq;                            // WP == 3
+                else pw = pw * sq;                               // chi2^k * sqrt(chi2), exactly 0 at chi2 == 0
             }
             w[o] = pw * e;
             if (TAIL) w[o] = (j < M) ? w[o] : 0.0;

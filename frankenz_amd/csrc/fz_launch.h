@@ -104,11 +104,14 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 }
 
 // the weight-space kernel body is used for the chi2^(k/2) likelihoods of the exact band counts
-// (4, 5, 6 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
+// (4, 5, 6, 8 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
 // the ln-space body measured as fast or faster for 5 and 6 bands, so the weight-space body is
-// instantiated there only for 4 bands (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
+// instantiated there only for 4 bands; at 8 bands only mode Ai keeps it (register budget)
+// (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
 template <class SRC>
-constexpr bool fz_has_wspace() { return SRC::WPOW >= 1 && SRC::WPOW <= 4 && (SRC::LMODE != 2 || SRC::NB == 4); }
+constexpr bool fz_has_wspace() {
+    return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB == 4) && (SRC::NB < 8 || SRC::LMODE == 1);
+}
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
     if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE");
@@ -176,7 +179,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
                 if (r <= 0) return r;
             }
         }
-        if constexpr (SRC::TILE < 256) {
+        if constexpr (SRC::NB > 16) {
             // wide records (17-32 bands): one object per wave keeps the kernel inside the register file
             r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else if constexpr (SRC::HAS_PRIOR) {
@@ -190,6 +193,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             // 2 objects (128 VGPRs) for the weight-space body and every ln-space body except
             // unmasked mode A and masked mode B, which want the 256-VGPR budget of 8 waves x 4
             if (tw == 4 && (fz_use_wspace(src) || SRC::PREF_2x16)) { tw = 2; nw = 16; }
+            else if (tw == 4 && SRC::PREF_2x8) { tw = 2; nw = 8; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
