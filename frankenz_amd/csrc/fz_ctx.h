@@ -184,6 +184,7 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
 FZ_DECL_BT(4)
 FZ_DECL_BT(5)
 FZ_DECL_BT(6)
+FZ_DECL_BT(7)
 FZ_DECL_BT(8)
 FZ_DECL_BT(16)
 FZ_DECL_BT(32)

@@ -1,7 +1,7 @@
 // Per-band-count instantiations of the photometric kernels.  Compiled once per
-// FZ_BT in {4, 5, 6, 8, 16, 32} (separate translation units so they build in parallel).
+// FZ_BT in {4, 5, 6, 7, 8, 16, 32} (separate translation units so they build in parallel).
 #ifndef FZ_BT
-#error "compile with -DFZ_BT=4|5|6|8|16|32"
+#error "compile with -DFZ_BT=4|5|6|7|8|16|32"
 #endif
 #include "fz_ctx.h"
 #include "fz_kernels.h"
@@ -14,9 +14,9 @@ using namespace fz;
 #define FZ_CAT(a, b) FZ_CAT_(a, b)
 #define FZ_NAME(base) FZ_CAT(base, FZ_BT)
 
-// VAR_FAST exists only when BT can equal the real band count (B in {4, 5, 6, 8}): padded band
+// VAR_FAST exists only when BT can equal the real band count (B in 4..8): padded band
 // counts always carry mask bits.
-#define FZ_EXACT_BT (FZ_BT == 4 || FZ_BT == 5 || FZ_BT == 6 || FZ_BT == 8)
+#define FZ_EXACT_BT (FZ_BT >= 4 && FZ_BT <= 8)
 #if FZ_EXACT_BT
 #define FZ_SWITCH_VAR(MODE_, CALL)                                         \
     switch (var) {                                                         \

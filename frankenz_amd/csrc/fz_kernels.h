@@ -48,7 +48,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr int LMODE = MODE;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
     static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST));
-    static constexpr bool PREF_2x8 = (BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
+    static constexpr bool PREF_2x8 = (BT == 7 || BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {

@@ -110,7 +110,7 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 // (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
 template <class SRC>
 constexpr bool fz_has_wspace() {
-    return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB == 4) && (SRC::NB < 8 || SRC::LMODE == 1);
+    return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB == 4) && (SRC::NB < 7 || SRC::LMODE == 1);
 }
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
