@@ -514,3 +514,30 @@ def test_masked_and_unmasked_objects_split_across_kernels(kw, monkeypatch):
     pick = np.concatenate([masked, full, [17]])
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p0[pick], rp, rtol=1e-8, atol=1e-14); close(lm0[pick], rlm); close(le0[pick], rle)
+
+
+def test_split_chunk_falls_back_as_a_whole_when_the_workspace_is_too_small():
+    """object subsets exist only for the single-pass kernel: without room for its candidate lists
+    the whole mixed chunk takes the two-pass route, masked variant."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(322)
+    M, N, B = 500, 6000, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    Xm[rs.rand(N, B) < 0.05] = 0
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    eng = get_engine()
+    out = {}
+    for name, lim in (('fused', 32 << 30), ('twopass', 1 << 20)):
+        eng.set_workspace_limit(lim)
+        try:
+            out[name] = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
+                                                          return_gof=True, save_fits=False, verbose=False)
+        finally:
+            eng.set_workspace_limit(32 << 30)
+    (p1, (lm1, le1)), (p2, (lm2, le2)) = out['fused'], out['twopass']
+    close(p1, p2, rtol=1e-9, atol=1e-15); close(lm1, lm2, rtol=1e-12); close(le1, le2, rtol=1e-12)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_dict=od)
+    close(p2[:40], rp, rtol=1e-8, atol=1e-14)
