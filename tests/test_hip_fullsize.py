@@ -11,11 +11,15 @@ pytestmark = pytest.mark.gpu
 SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
 
 
-def problem(n, m, seed=20260101):
+def problem(n, m, seed=20260101, varying_errors=False, mask_frac=0.0):
     rs = np.random.RandomState(seed)
     Y = rs.lognormal(1., 1., size=(m, 5)); Ye = np.tile(SDSS_SIGMA, (m, 1)); Ym = np.ones((m, 5))
+    if varying_errors:                      # per-model errors: the general mode A kernels
+        Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
     X = Y[rs.randint(0, m, n)] + SDSS_SIGMA * rs.standard_normal((n, 5))
     Xe = np.tile(SDSS_SIGMA, (n, 1)); Xm = np.ones((n, 5))
+    if mask_frac > 0:                       # mixed chunks: split between mask-free and masked kernels
+        Xm[np.random.RandomState(5).rand(n, 5) < mask_frac] = 0.0
     return Y, Ye, Ym, X, Xe, Xm, rs.uniform(0, 6, m), np.full(m, 0.05)
 
 
@@ -25,11 +29,13 @@ def dicts():
     return PDFDict(grid, sg), fo.KernelDict(grid, sg)
 
 
-@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}])
-def test_config2_fused_properties_and_sample_parity(kw):
+@pytest.mark.parametrize('kw,prob', [({}, {}), ({'free_scale': True, 'ignore_model_err': True}, {}),
+                                     ({}, {'varying_errors': True}), ({}, {'mask_frac': 0.02}),
+                                     ({'dim_prior': False}, {'varying_errors': True, 'mask_frac': 0.02})])
+def test_config2_fused_properties_and_sample_parity(kw, prob):
     from frankenz_amd import BruteForce
     n, m = 100000, 100000
-    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, **prob)
     d, od = dicts()
     bf = BruteForce(Y, Ye, Ym)
     Xc, Xec, Xmc = X.copy(), Xe.copy(), Xm.copy()
