@@ -2,6 +2,8 @@
 routes: BruteForce.fit_predict (fused) and fit + predict (planes) against the oracle.  Small
 problems, many combinations -- aimed at boundary handling (partial waves / tiles, padded bands,
 masked-out objects, objects with no usable band)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ def rows_defined(a, b):
     return np.isfinite(a).all(axis=1) & np.isfinite(b).all(axis=1)
 
 
-@pytest.mark.parametrize('seed', range(160))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('FZ_FUZZ_SEEDS', 160))))
 def test_random_configuration(seed):
     from frankenz_amd import BruteForce
     d, od = dicts()
@@ -77,7 +79,7 @@ def test_random_configuration(seed):
     np.testing.assert_allclose(p2[ok2], rp[ok2], rtol=2e-7, atol=1e-13)
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('FZ_FUZZ_KNN_SEEDS', 40))))
 def test_random_knn_configuration(seed):
     """NearestNeighbors: random sizes, K, k, feature maps, likelihood modes, optional ln-prior."""
     from frankenz_amd import NearestNeighbors
