@@ -628,7 +628,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     const bool cdf = !ko->use_wt_thresh;          // reference CDF rule: materialise the chunk's ln-like rows
     PriorBind pb; PriorGuard guard{c};
     FZCHK(prior_begin(c, pr, N, M, pb));
-    int64_t nc = std::min<int64_t>(N, getenv("FZ_CHUNK") ? atoll(getenv("FZ_CHUNK")) : (1 << 18));
+    int64_t nc = std::min<int64_t>(N, getenv("FZ_CHUNK") ? atoll(getenv("FZ_CHUNK")) : (1 << 20));   // the fused kernel's workspace does not grow with the chunk
     const int64_t per_obj = M * 8 * (mode == 3 ? 4 : (cdf ? 1 : 0)) + pb.chunk_bytes_per_obj;
     if (per_obj) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / per_obj));
     for (int64_t i0 = 0; i0 < N; i0 += nc) {
