@@ -35,6 +35,13 @@ extern "C" int fz_ctx_create(int device, fz_ctx** out) {
     hipDeviceProp_t pr;
     HIPCHK(hipGetDeviceProperties(&pr, device));
     c->cu_count = pr.multiProcessorCount;
+    // workspace budget (candidate lists, staging planes): 45 % of the device memory, at least the
+    // old fixed 32 GiB figure where the part allows it -- 130 GB on a 288-GB MI355X, which is what
+    // the single-pass kernel wants for a 1e6-model set.  Allocation stays on demand.
+    {
+        const int64_t total = (int64_t)pr.totalGlobalMem;
+        c->ws_limit = std::max<int64_t>(std::min<int64_t>((int64_t)32 << 30, total / 2), (int64_t)(0.45 * (double)total));
+    }
     *out = c;
     return 0;
 }

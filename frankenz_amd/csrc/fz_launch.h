@@ -88,8 +88,9 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     int64_t blocks = need;
     if (need > c->cu_count) {
         const int64_t k = std::min<int64_t>(blocks_per_cu, fit / c->cu_count);
-        if (k < 1) return 1;                                       // cannot fill the chip
-        blocks = std::min<int64_t>(need, k * c->cu_count);
+        if (k >= 1) blocks = std::min<int64_t>(need, k * c->cu_count);
+        else if (fit >= c->cu_count / 2) blocks = fit;             // very large model sets: part of the chip still beats two passes
+        else return 1;                                             // cannot fill even half the chip
     } else if (fit < need) return 1;
     if (c->d_cand.ensure((size_t)blocks * NW * per_wave) != 0) return 1;      // no room for the lists: two-pass route
     FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));

@@ -71,7 +71,8 @@ void fz_ctx_destroy(fz_ctx* ctx);
 int  fz_sync(fz_ctx* ctx);
 int  fz_timing_reset(fz_ctx* ctx);
 int  fz_timing_get(fz_ctx* ctx, fz_timing* out);
-/* byte budget for internal (N x M) work planes (mode C state, host staging). */
+/* byte budget for internal work space (candidate lists of the single-pass kernel, (N x M)
+ * planes of mode C, host staging); default 45 % of the device memory, allocated on demand. */
 int  fz_set_workspace_limit(fz_ctx* ctx, int64_t bytes);
 
 /* BruteForce.__init__ (bruteforce.py:36-64): the model set (M,B) x3. */
