@@ -84,10 +84,12 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Mp) return;
     uint32_t bt = 0; int fl = 0;
+    double ysum = 0.0;
     for (int b = 0; b < BT; ++b) {
         double vy = 0.0, ve2 = 0.0, ve = 0.0;
         if (j < M && b < B) {
             vy = y[j * B + b];
+            ysum += fabs(vy);
             const double e = ye[j * B + b];
             ve2 = e * e; ve = e;
             if (!(e == ye[b])) fl |= 8;                        // vs model 0 (nan counts as different)
@@ -105,6 +107,9 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
     for (int b = 2 * BT; b < rw0; ++b) rec0[j * rw0 + b] = 0.0;
     for (int b = BT; b < rw1; ++b) rec1[j * rw1 + b] = 0.0;
     bits[j] = bt;
+    // an all-zero model makes the free-scale solve 0/0 (nan scale and ln-like, as in the reference):
+    // such sets take the IEEE variant, which keeps the nan bookkeeping the fast variants drop
+    if (j < M && !(ysum > 0.0)) fl |= 4;
     if (fl) atomicOr(flags, fl);
 }
 

@@ -46,6 +46,9 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr bool HAS_PRIOR = PRI;
     static constexpr int NB = BT;
     static constexpr int LMODE = MODE;
+    // mask-free tame data cannot produce a nan ln-like (chi2 is finite and >= 0, the exponent of the
+    // dimensionality prior is positive): the nan bookkeeping of the ln-space body is compiled out
+    static constexpr bool NO_NAN = (VAR == VAR_FAST) && !PRI;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
     static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST));
     static constexpr bool PREF_2x8 = (BT == 7 || BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
@@ -427,7 +430,9 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
         }
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            if (l[o] != l[o]) { fs.anynan |= 1u << o; if (j == 0) fs.firstnan |= 1u << o; }
+            if constexpr (!SRC::NO_NAN) {
+                if (l[o] != l[o]) { fs.anynan |= 1u << o; if (j == 0) fs.firstnan |= 1u << o; }
+            }
             ms_push(fs.st[o], l[o], tb);
         }
 #pragma unroll

@@ -541,3 +541,25 @@ def test_split_chunk_falls_back_as_a_whole_when_the_workspace_is_too_small():
     close(p1, p2, rtol=1e-9, atol=1e-15); close(lm1, lm2, rtol=1e-12); close(le1, le2, rtol=1e-12)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_dict=od)
     close(p2[:40], rp, rtol=1e-8, atol=1e-14)
+
+
+def test_all_zero_model_poisons_free_scale_like_the_reference():
+    """a model whose fluxes are all zero has shape == 0: the free-scale solve is 0/0, its ln-like is
+    nan, and with it every object's evidence and PDF (bruteforce.py:619-620) -- not silently dropped."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(99)
+    M, N, B = 300, 20, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Y[7] = 0.0
+    Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(np.arange(10, M), N)] + 0.3 * rs.randn(N, B); Xe = np.full((N, B), 0.3); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    for kw in ({'free_scale': True, 'ignore_model_err': True}, {}):
+        p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                        return_gof=True, save_fits=False, verbose=False)
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+        np.testing.assert_array_equal(np.isnan(p), np.isnan(rp)); np.testing.assert_array_equal(np.isnan(le), np.isnan(rle))
+        ok = np.isfinite(rle)
+        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(le[ok], rle[ok])
+        if kw:
+            assert np.isnan(rle).all() and np.isnan(le).all()
