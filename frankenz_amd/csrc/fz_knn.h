@@ -86,6 +86,108 @@ __global__ __launch_bounds__(256) void k_knn_query(const float* __restrict__ fea
 }
 
 // ---------------------------------------------------------------------------
+// The same search for the Euclidean norm with an fp32 SCREEN: the squared distances of two
+// queries at a time are formed with packed fp32 (v_pk_add_f32 / v_pk_fma_f32: twice the fp64
+// rate), compared with an admission bar that is provably above the exact one, and only the
+// rare lanes that pass recompute their distance in fp64 for the exact test -- so the result is
+// the exact fp64 top-k of k_knn_query, bit for bit.
+//
+// Bar: the features are float32 already; the query q is rounded to qf = float(q) with
+// |q - qf| <= delta = 2^-24 max|q|.  If D^2 = sum (q-p)^2 < tau then
+// sum (qf-p)^2 <= (sqrt(tau) + sqrt(F) delta)^2 = tau + 2 sqrt(F tau) delta + F delta^2, and the
+// fp32 evaluation of that sum carries a relative error below (F+2) 2^-24 < 1e-6.
+// ---------------------------------------------------------------------------
+typedef float fz_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float knn_bar32(double tau, double delta, int F) {
+    if (!(tau < 1e300)) return INFINITY;
+    const double b = (tau + 2.0 * sqrt((double)F * tau) * delta + (double)F * delta * delta) * (1.0 + 4e-6);
+    float f = (float)b;
+    if ((double)f < b) f = __uint_as_float(__float_as_uint(f) + 1u);      // next float up (f is positive and finite here)
+    return f;
+}
+
+template <int FT, int TQ>
+__global__ __launch_bounds__(256) void k_knn_query32(const float* __restrict__ feats, int64_t Mp, int M,
+                                                     const double* __restrict__ q, int64_t N, int F, int k,
+                                                     double bound2, int64_t* __restrict__ idx, int K) {
+    static_assert(TQ % 2 == 0, "queries are screened in pairs");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * TQ;
+    if (i0 >= N) return;
+    const int tree = blockIdx.y;
+    const float* ft = feats + (size_t)tree * FT * Mp;
+    double qv[TQ][FT], delta[TQ];
+    fz_f2 qp[TQ / 2][FT];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int64_t i = i0 + u < N ? i0 + u : N - 1;
+        double mx = 0.0;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) { qv[u][f] = f < F ? q[i * F + f] : 0.0; mx = fmax(mx, fabs(qv[u][f])); }
+        delta[u] = mx * 6.0e-8;                                   // >= 2^-24 max|q|
+    }
+#pragma unroll
+    for (int h = 0; h < TQ / 2; ++h)
+#pragma unroll
+        for (int f = 0; f < FT; ++f) qp[h][f] = fz_f2{(float)qv[2 * h][f], (float)qv[2 * h + 1][f]};
+    double ld[TQ], tau[TQ];
+    float bar[TQ];
+    int lj[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) { ld[u] = INFINITY; lj[u] = M; tau[u] = bound2; bar[u] = knn_bar32(bound2, delta[u], F); }
+
+    for (int jb = 0; jb < M; jb += 64) {
+        const int j = jb + lane;
+        float p[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) p[f] = ft[(size_t)f * Mp + j];             // Mp padded: always in range
+        fz_f2 acc[TQ / 2];
+#pragma unroll
+        for (int h = 0; h < TQ / 2; ++h) {
+            fz_f2 a = {0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < FT; ++f) { const fz_f2 d = qp[h][f] - fz_f2{p[f], p[f]}; a = __builtin_elementwise_fma(d, d, a); }
+            acc[h] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            const float s32 = (u & 1) ? acc[u >> 1].y : acc[u >> 1].x;
+            const bool pass = j < M && s32 < bar[u];               // nan never passes (as in the exact test)
+            if (!__any(pass)) continue;                            // the common case after warm-up
+            double d2 = INFINITY;
+            if (pass) {                                            // exact distance, only in the lanes that passed
+                d2 = 0.0;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) { const double d = qv[u][f] - (double)p[f]; d2 = fma(d, d, d2); }
+            }
+            unsigned long long mask = __ballot(pass && d2 < tau[u]);
+            while (mask) {
+                const int sl = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double dn = __shfl(d2, sl, 64);
+                if (!(dn < tau[u])) continue;                      // bar moved while draining this step
+                const int jn = jb + sl;
+                const int pos = __builtin_popcountll(__ballot(lane < k && ld[u] <= dn));
+                const double ud = __shfl_up(ld[u], 1, 64);
+                const int uj = __shfl_up(lj[u], 1, 64);
+                if (lane > pos) { ld[u] = ud; lj[u] = uj; }
+                else if (lane == pos) { ld[u] = dn; lj[u] = jn; }
+                const double kth = __shfl(ld[u], k - 1, 64);
+                tau[u] = kth < bound2 ? kth : bound2;
+                bar[u] = knn_bar32(tau[u], delta[u], F);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int64_t i = i0 + u;
+        if (i < N && lane < k) idx[(i * K + tree) * k + lane] = (ld[u] < bound2) ? lj[u] : M;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // subset likelihood + PDF, one object per wave
 // ---------------------------------------------------------------------------
 #define FZ_KNN_HASH 1024          // open-addressing table slots (>= 2 * W)

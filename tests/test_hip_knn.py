@@ -183,3 +183,37 @@ def test_knn_wide_band_set():
     np.testing.assert_allclose(nn.fit_lnprob, rlnp, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(p, rp, rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(le, rle, rtol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scale', [1.0, 1e4, 1e-3])
+def test_screened_search_is_the_exact_search(scale, monkeypatch):
+    """the packed-fp32 screen + fp64 re-check returns the same neighbour table as the all-fp64
+    search (FZ_KNN_FP64=1), also with near-duplicate models, features far from the origin (where
+    rounding the query to fp32 costs the most) and tiny features."""
+    from frankenz_amd.engine import get_engine
+    rs = np.random.RandomState(int(scale * 7) % 1000 + 3)
+    K, M, F, N, k = 3, 5000, 5, 300, 20
+    base = rs.normal(20.0, 1.0, size=(M, F))
+    base[1000:2000] = base[:1000] + rs.normal(0, 1e-6, size=(1000, F))       # near ties at the fp32 resolution
+    feats = np.stack([(base + rs.normal(0, 0.01, size=(M, F))) * scale for _ in range(K)]).astype(np.float32)
+    q = (base[rs.choice(M, N)] + rs.normal(0, 0.02, size=(N, F))) * scale
+    eng = get_engine()
+    eng.upload_models(np.ones((M, F)), np.zeros((M, F)), np.ones((M, F)))       # the search only needs their count
+    eng.knn_upload_trees(feats)
+    out = {}
+    for name in ('screen', 'fp64'):
+        if name == 'fp64':
+            monkeypatch.setenv('FZ_KNN_FP64', '1')
+        idx = np.empty((N, K * k), dtype=np.int64)
+        eng.knn_query(np.ascontiguousarray(q), k, np.inf, idx)
+        out[name] = idx
+    monkeypatch.delenv('FZ_KNN_FP64')
+    np.testing.assert_array_equal(out['screen'], out['fp64'])
+    # and both equal a float64 brute force on the host for a few queries
+    for i in (0, 7, 123):
+        for t in range(K):
+            d2 = ((q[i][None, :] - feats[t].astype(np.float64)) ** 2).sum(axis=1)
+            want = np.argsort(d2, kind='stable')[:k]
+            got = out['screen'][i, t * k:(t + 1) * k]
+            np.testing.assert_array_equal(np.sort(d2[got]), np.sort(d2[want]))
