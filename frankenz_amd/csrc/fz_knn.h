@@ -151,11 +151,18 @@ __global__ __launch_bounds__(256) void k_knn_query32(const float* __restrict__ f
             for (int f = 0; f < FT; ++f) { const fz_f2 d = qp[h][f] - fz_f2{p[f], p[f]}; a = __builtin_elementwise_fma(d, d, a); }
             acc[h] = a;
         }
+        bool passu[TQ], anyp = false;
 #pragma unroll
         for (int u = 0; u < TQ; ++u) {
             const float s32 = (u & 1) ? acc[u >> 1].y : acc[u >> 1].x;
-            const bool pass = j < M && s32 < bar[u];               // nan never passes (as in the exact test)
-            if (!__any(pass)) continue;                            // the common case after warm-up
+            passu[u] = j < M && s32 < bar[u];                      // nan never passes (as in the exact test)
+            anyp |= passu[u];
+        }
+        if (!__any(anyp)) continue;                                // the common case after warm-up: one test per step
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            const bool pass = passu[u];
+            if (!__any(pass)) continue;
             double d2 = INFINITY;
             if (pass) {                                            // exact distance, only in the lanes that passed
                 d2 = 0.0;
