@@ -105,9 +105,9 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 }
 
 // the weight-space kernel body is used for the chi2^(k/2) likelihoods of the exact band counts
-// (4, 5, 6, 8 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
+// (4-8 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
 // the ln-space body measured as fast or faster for 5 and 6 bands, so the weight-space body is
-// instantiated there only for 4 bands; at 8 bands only mode Ai keeps it (register budget)
+// instantiated there only for 4 bands; from 7 bands up only mode Ai keeps it (register budget)
 // (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
 template <class SRC>
 constexpr bool fz_has_wspace() {
@@ -190,9 +190,10 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             else r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
             int tw = (n >= (int64_t)c->cu_count * 64) ? 4 : 1, nw = (tw == 1) ? 4 : 8;
-            // measured best geometry per kernel body (profiles/README.md, r1_v5 sweep): 16 waves x
+            // measured best geometry per kernel body (profiles/README.md): up to 6 bands 16 waves x
             // 2 objects (128 VGPRs) for the weight-space body and every ln-space body except
-            // unmasked mode A and masked mode B, which want the 256-VGPR budget of 8 waves x 4
+            // unmasked mode A and masked mode B, which want the 256-VGPR budget of 8 waves x 4;
+            // wider records spill at 128 VGPRs (PREF_2x16 / PREF_2x8 in PhotSrc)
             if (tw == 4 && (fz_use_wspace(src) || SRC::PREF_2x16)) { tw = 2; nw = 16; }
             else if (tw == 4 && SRC::PREF_2x8) { tw = 2; nw = 8; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
