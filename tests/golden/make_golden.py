@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-Generate the golden fixtures by IMPORTING THE REFERENCE.
+Generate the golden fixtures (SURVEY.md section 8c, G1-G7, and G8-G11 for the section 8f rows) by IMPORTING THE REFERENCE.
 
 Run in the build container only (the reference never travels to the GPU box):
 
@@ -521,4 +521,4 @@ if __name__ == '__main__':
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
-    g1(); g2(); g3(); g4(); g5(); g6(); g7()
+    g1(); g2(); g3(); g4(); g5(); g6(); g7(); g8(); g9(); g10(); g11()
