@@ -270,8 +270,7 @@ def main():
                               "roofline": {"bound": "mfma", "kernel": "k_gemm_f64", "achieved": flops / dt / 1e12,
                                            "peak": 78.6, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 78.6,
                                            "note": "whole call (normalise + GEMM + statistics) over the GEMM's 2 N G^2 flops"}}))
-            return
-        if args.workload == "fit":
+        elif args.workload == "fit":
             ms = tm["ms_planes"] / max(tm["n_planes"], 1)
             per_launch = N * M / (max(tm["n_planes"], 1) / args.steps)
             gbs = per_launch * 16 / (ms * 1e-3) / 1e9
@@ -291,9 +290,8 @@ def main():
                               "kernel_ms_per_step": tm["ms_knn"] / args.steps, "pdfs_normalised": ok,
                               "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "NearestNeighbors.fit_predict: %d objects x %d models, K=25 k=20" % (N, M)}}))
-        return
 
-    if rank == 0:
+    if rank == 0 and args.workload == "fit_predict":
         evals = float(world) * N * M * args.steps
         value = evals / dt
         # dominant kernel, HIP events on the library's own stream (per launch)
