@@ -52,7 +52,7 @@ def test_config2_fused_properties_and_sample_parity(kw, prob):
     np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_array_equal(le2, le[sl])
     np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)               # LDS float atomics: order may differ
     # oracle on a random sample of objects against the FULL model set
-    pick = np.random.RandomState(1).choice(n, 24, replace=False)
+    pick = np.random.RandomState(1).choice(n, 100, replace=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
     np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
