@@ -103,3 +103,28 @@ def test_clean_is_idempotent_and_matches_reference_rule():
     a2, b2, c2 = a.copy(), b.copy(), c.copy()
     eng.clean(a2, b2, c2)
     np.testing.assert_array_equal(a2, a); np.testing.assert_array_equal(b2, b); np.testing.assert_array_equal(c2, c)
+
+
+def test_config3_full_size_one_million_objects():
+    """BASELINE configs[2] at its full size, 1e6 objects x 1e5 models (the bench workload) through
+    the drop-in class with host arrays: normalisation, max <= evidence <= max + ln M, shard
+    invariance of a slice, oracle parity on a sample."""
+    from frankenz_amd import BruteForce
+    n, m = 1000000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
+    d, od = dicts()
+    bf = BruteForce(Y, Ye, Ym)
+    p, (lm, le) = bf.fit_predict(X, Xe, Xm, z, ze, label_dict=d, return_gof=True, save_fits=False, verbose=False)
+    assert p.shape == (n, 701)
+    s = p.sum(axis=1)
+    assert np.isfinite(s).all() and np.abs(s - 1.0).max() < 1e-12 and p.min() >= 0.0
+    assert np.all(le >= lm - 1e-12) and np.all(le <= lm + np.log(m) + 1e-9)
+    sl = slice(777777, 777777 + 3000)
+    p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d, return_gof=True,
+                                    save_fits=False, verbose=False)
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_array_equal(le2, le[sl])
+    np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)
+    pick = np.random.RandomState(2).choice(n, 40, replace=False)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9); np.testing.assert_allclose(le[pick], rle, rtol=1e-9)
+    np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
