@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, '.')
 import bench
 from frankenz_amd import BruteForce, PDFDict
-N, M = 200000, 100000
+N, M = 1000000, 100000
 Y, Ye, Ym, X, Xe, Xm, z, ze = bench.make_problem(N, M, 1)
 d = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
 bf = BruteForce(Y, Ye, Ym)
