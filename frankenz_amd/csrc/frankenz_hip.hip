@@ -32,6 +32,11 @@ extern "C" int fz_ctx_create(int device, fz_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
+    }
     hipDeviceProp_t pr;
     HIPCHK(hipGetDeviceProperties(&pr, device));
     c->cu_count = pr.multiProcessorCount;
@@ -51,7 +56,12 @@ extern "C" void fz_ctx_destroy(fz_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : c->all_bufs()) b->release();
+    (void)hipStreamSynchronize(c->copy_stream);
+    timer_flush(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_done[k]); (void)hipEventDestroy(c->ev_copied[k]); }
+    (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -643,17 +653,57 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     int64_t nc = std::min<int64_t>(N, getenv("FZ_CHUNK") ? atoll(getenv("FZ_CHUNK")) : (1 << 20));   // the fused kernel's workspace does not grow with the chunk
     const int64_t per_obj = M * 8 * (mode == 3 ? 4 : (cdf ? 1 : 0)) + pb.chunk_bytes_per_obj;
     if (per_obj) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / per_obj));
-    for (int64_t i0 = 0; i0 < N; i0 += nc) {
+    // Host PDFs are the bulk of the PCIe traffic of the drop-in call (5.6 GB at 1e6 objects, longer
+    // than the kernel).  Pipeline: chunks of 2^18 objects, two device staging buffers, chunk k's rows
+    // leave on a second stream while chunk k+1 is being computed; kernel timing is deferred so that
+    // the host does not wait on a kernel before it has queued the previous chunk's copy.
+    const bool pipe = !pdf_dev && mode != 3 && !cdf && N >= (3 << 17) && !getenv("FZ_NO_PIPELINE");
+    if (pipe) nc = std::min<int64_t>(nc, 1 << 18);
+    struct PipeGuard {
+        fz_ctx* c; bool on;
+        ~PipeGuard() { if (on) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); c->defer_timing = false; timer_flush(c); } }
+    } pguard{c, pipe};
+    if (pipe) {
+        c->defer_timing = true;
+        if (lmap && !lm_dev) FZCHK(c->d_lmap.ensure((size_t)N * 8));          // whole-run gof buffers: copied once at the end
+        if (levid && !le_dev) FZCHK(c->d_levid.ensure((size_t)N * 8));
+    }
+    int64_t prev_i0 = -1, prev_n = 0; int prev_b = 0;
+    auto ship_prev = [&]() -> int {                                // queue the previous chunk's rows behind its kernel
+        if (prev_i0 < 0) return 0;
+        DevBuf& st = prev_b ? c->d_pdfs2 : c->d_pdfs;
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[prev_b], 0));
+        HIPCHK(hipMemcpyAsync(pdfs + prev_i0 * G, st.p, (size_t)prev_n * G * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipEventRecord(c->ev_copied[prev_b], c->copy_stream));
+        prev_i0 = -1;
+        return 0;
+    };
+    int64_t kchunk = 0;
+    for (int64_t i0 = 0; i0 < N; i0 += nc, ++kchunk) {
         const int64_t n = std::min(nc, N - i0);
+        const int bsel = pipe ? (int)(kchunk & 1) : 0;
         ObjChunk ch; int fl = 0;
         FZCHK(prep_chunk(c, x, xe, xm, i0, n, obj_vmode(c, like_mode(o)), true, ch, fl));
         FZCHK(prior_chunk(c, pb, i0, n, M));
         const int var = pick_var(c, fl);
         const bool masked = var != VAR_FAST;
         double* d_pdf; double* d_lm; double* d_le;
-        if (pdf_dev) d_pdf = pdfs + i0 * G; else { FZCHK(c->d_pdfs.ensure((size_t)n * G * 8)); d_pdf = c->d_pdfs.as<double>(); }
+        if (pdf_dev) d_pdf = pdfs + i0 * G;
+        else {
+            DevBuf& st = bsel ? c->d_pdfs2 : c->d_pdfs;
+            if (pipe && kchunk >= 2) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[bsel], 0));     // its previous rows have left
+            if (st.cap < (size_t)n * G * 8) { if (pipe) HIPCHK(hipStreamSynchronize(c->copy_stream)); FZCHK(st.ensure((size_t)n * G * 8)); }
+            d_pdf = st.as<double>();
+        }
+        if (pipe) {
+            d_lm = (lmap && lm_dev) ? lmap + i0 : c->d_lmap.as<double>() + ((lmap && !lm_dev) ? i0 : 0);
+            d_le = (levid && le_dev) ? levid + i0 : c->d_levid.as<double>() + ((levid && !le_dev) ? i0 : 0);
+            if (!lmap) { FZCHK(c->d_lmap.ensure((size_t)n * 8)); d_lm = c->d_lmap.as<double>(); }
+            if (!levid) { FZCHK(c->d_levid.ensure((size_t)n * 8)); d_le = c->d_levid.as<double>(); }
+        } else {
         if (lmap && lm_dev) d_lm = lmap + i0; else { FZCHK(c->d_lmap.ensure(n * 8)); d_lm = c->d_lmap.as<double>(); }
         if (levid && le_dev) d_le = levid + i0; else { FZCHK(c->d_levid.ensure(n * 8)); d_le = c->d_levid.as<double>(); }
+        }
         if (mode == 3) {
             FZCHK(run_modec(c, var, n, o));
             double* lpl = c->d_mc[1].as<double>();
@@ -698,9 +748,22 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
             }
             if (!done) FZCHK(run_fitpredict(c, mode, var, o->dim_prior, n, ko, d_lm, d_le, d_pdf));
         }
+        if (pipe) {
+            HIPCHK(hipEventRecord(c->ev_done[bsel], c->stream));          // chunk k is queued ...
+            FZCHK(ship_prev());                                            // ... chunk k-1 leaves while it runs
+            prev_i0 = i0; prev_n = n; prev_b = bsel;
+            continue;
+        }
         if (!pdf_dev) FZCHK(copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8));
         if (lmap && !lm_dev) FZCHK(copy_out(c, lmap + i0, d_lm, n * 8));
         if (levid && !le_dev) FZCHK(copy_out(c, levid + i0, d_le, n * 8));
+    }
+    if (pipe) {
+        FZCHK(ship_prev());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        if (lmap && !lm_dev) FZCHK(copy_out(c, lmap, c->d_lmap.p, (size_t)N * 8));
+        if (levid && !le_dev) FZCHK(copy_out(c, levid, c->d_levid.p, (size_t)N * 8));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

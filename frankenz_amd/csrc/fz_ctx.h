@@ -51,6 +51,14 @@ struct fz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // host-PDF pipeline of fit_predict: chunk k's rows leave on copy_stream while chunk k+1 is computed
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    // deferred kernel timing (no host block inside that pipeline): event pairs resolved by timer_flush
+    bool defer_timing = false;
+    struct PendingTime { hipEvent_t a, b; double* ms; int64_t* n; };
+    std::vector<PendingTime> pending;
+    std::vector<hipEvent_t> ev_pool;
     fz_timing tm{};
     int64_t ws_limit = (int64_t)32 << 30;
     int cu_count = 256;
@@ -71,7 +79,7 @@ struct fz_ctx {
     DevBuf d_pos, d_cls, d_norm, d_ly, d_lstd, d_lo, d_hi, d_grid;
     // per-chunk object buffers
     DevBuf d_rx, d_rxe, d_rxm, d_ox, d_ov, d_obits, d_oslv, d_flags;
-    DevBuf d_lmap, d_levid, d_pdfs;
+    DevBuf d_lmap, d_levid, d_pdfs, d_pdfs2;
     DevBuf d_pl[7];            // staging planes
     DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt;
     DevBuf d_cand, d_kv, d_olstats;
@@ -89,7 +97,7 @@ struct fz_ctx {
     std::vector<DevBuf*> all_bufs() {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
                                   &d_cls, &d_norm, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
-                                  &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_mcerr,
+                                  &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_kv, &d_olstats, &d_omap, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm};
         for (auto& b : d_pl) v.push_back(&b);
         for (auto& b : d_mc) v.push_back(&b);
@@ -105,17 +113,37 @@ inline bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-// HIP-event bracket on the ctx stream, accumulated per kernel family
+// HIP-event bracket on the ctx stream, accumulated per kernel family.  Normally the destructor waits
+// for the kernel (the figure is needed at once and the next host step would wait anyway); with
+// c->defer_timing the pair is queued and resolved later by timer_flush, so the host can go on.
 struct Timer {
     fz_ctx* c; double* ms; int64_t* n;
-    Timer(fz_ctx* c_, double* ms_, int64_t* n_) : c(c_), ms(ms_), n(n_) { (void)hipEventRecord(c->ev0, c->stream); }
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t take(fz_ctx* c) {
+        if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+    }
+    Timer(fz_ctx* c_, double* ms_, int64_t* n_) : c(c_), ms(ms_), n(n_) {
+        if (c->defer_timing) { a = take(c); b = take(c); (void)hipEventRecord(a, c->stream); }
+        else (void)hipEventRecord(c->ev0, c->stream);
+    }
     ~Timer() {
+        if (a) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, ms, n}); return; }
         (void)hipEventRecord(c->ev1, c->stream);
         (void)hipEventSynchronize(c->ev1);
         float t = 0; (void)hipEventElapsedTime(&t, c->ev0, c->ev1);
         *ms += t; *n += 1;
     }
 };
+inline void timer_flush(fz_ctx* c) {
+    for (auto& p : c->pending) {
+        (void)hipEventSynchronize(p.b);
+        float t = 0; (void)hipEventElapsedTime(&t, p.a, p.b);
+        *p.ms += t; *p.n += 1;
+        c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
 
 // copies with either side on host or device, ordered on the ctx stream
 inline int copy_in(fz_ctx* c, void* dst_dev, const void* src, size_t bytes) {

@@ -563,3 +563,33 @@ def test_all_zero_model_poisons_free_scale_like_the_reference():
         close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(le[ok], rle[ok])
         if kw:
             assert np.isnan(rle).all() and np.isnan(le).all()
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_host_pdf_pipeline_matches_the_serial_copy_out(masked, monkeypatch):
+    """calls with host PDFs and >= 3*2^17 objects run as a pipeline (2^18-object chunks, two
+    staging buffers, rows of chunk k copied out while chunk k+1 is computed, gof rows copied once
+    at the end): bit-identical to the serial path (FZ_NO_PIPELINE=1) and equal to the oracle on
+    rows of the first, a middle and the last (ragged) chunk."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(77)
+    M, N, B = 230, (1 << 18) * 2 + 12345, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = Y * rs.uniform(0.02, 0.08, size=(M, B)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    if masked:
+        Xm[rs.rand(N, B) < 0.02] = 0.
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    p1, (lm1, le1) = run()
+    monkeypatch.setenv('FZ_NO_PIPELINE', '1')
+    p0, (lm0, le0) = run()
+    monkeypatch.delenv('FZ_NO_PIPELINE')
+    if not masked:      # same launches per object either way (a split chunk's partition differs with the chunking)
+        np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(lm1, lm0); np.testing.assert_array_equal(le1, le0)
+    else:
+        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+    for sl in (slice(0, 20), slice((1 << 18) - 10, (1 << 18) + 10), slice(N - 20, N)):
+        rp, rlm, rle = fo.bruteforce_fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), Y, Ye, Ym, z, ze, label_dict=od)
+        close(p1[sl], rp, rtol=1e-8, atol=1e-14); close(lm1[sl], rlm); close(le1[sl], rle)
