@@ -40,11 +40,12 @@ MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True},
          "An": {"dim_prior": False}, "Bn": {"free_scale": True, "ignore_model_err": True, "dim_prior": False}}
 
 
-def make_problem(n_obj, n_model, seed, B=5):
+def make_problem(n_obj, n_model, seed, B=5, noise=1.0):
     """lognormal model fluxes, SDSS-depth noise (B != 5, a side
-    experiment of --nband: the five SDSS depths repeated / truncated)."""
+    experiment of --nband: the five SDSS depths repeated / truncated; noise != 1, a side
+    experiment of --noise-scale: broader likelihoods, so more models pass wt_thresh)."""
     rs = np.random.RandomState(seed)
-    sig = np.resize(SDSS_SIGMA, B)
+    sig = np.resize(SDSS_SIGMA, B) * noise
     Y = rs.lognormal(mean=1.0, sigma=1.0, size=(n_model, B))
     Ye = np.tile(sig, (n_model, 1))
     Ym = np.ones((n_model, B))
@@ -130,6 +131,8 @@ def main():
                          "(the general mode A kernels)")
     ap.add_argument("--nband", type=int, default=5, help="band count (headline: 5, the SDSS configuration)")
     ap.add_argument("--wt-thresh", type=float, default=1e-3, help="kde_kwargs wt_thresh (reference default 1e-3)")
+    ap.add_argument("--noise-scale", type=float, default=1.0,
+                    help="multiply the SDSS depths (side experiment: low-S/N objects keep far more models above wt_thresh)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -139,7 +142,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     kw = MODES[args.mode]
     N, M = args.nobj, args.nmodel
-    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband)
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband, args.noise_scale)
     if args.model_err == "varying":
         Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
@@ -320,7 +323,8 @@ def main():
                                    "dict KDE on 701-pt grid" % (N, M, args.nband, args.mode),
                        "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
-                       "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err},
+                       "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err,
+                       "noise_scale": args.noise_scale},
             "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "
                      "and mode A runs on the mode-Ai kernels; --model-err varying times the general mode A kernels"
                      if (args.model_err == "const" and args.mode in ("A", "An")) else None),
