@@ -239,27 +239,6 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     FZCHK(copy_in(c, c->d_cls.p, cls.data(), Mp * 4));
     FZCHK(copy_in(c, c->d_norm.p, nrm.data(), Mp * 8));
     c->single_cls = single; c->cls0 = (int32_t)hs[0]; c->w0 = (int32_t)c->h_widths[hs[0]];
-    if (single) {
-        // One kernel shape for every label: the edge-truncated mass depends on the grid index alone.
-        // Padded bins q = p + w cover every admissible p in [-w, G-1+w]; candidates carry q, the
-        // fused kernel accumulates raw weights per bin and applies 1/mass per bin afterwards.
-        const int64_t d = hs[0], w = c->h_widths[d], len = 2 * w + 1, acc = G + 2 * w;
-        const double* cdf = c->h_kcdf.data() + c->h_offsets[d];
-        std::vector<double> inv(acc);
-        for (int64_t q = 0; q < acc; ++q) {
-            const int64_t p = q - w;
-            const int64_t lo = std::max<int64_t>(p - w, 0), hi = std::min<int64_t>(p + w + 1, G);
-            const int64_t lpad = lo - (p - w), hpad = hi - (p + w + 1);
-            double mass = cdf[len + hpad - 1];
-            if (lpad != 0) mass -= cdf[lpad - 1];
-            inv[q] = 1.0 / mass;
-        }
-        std::vector<int32_t> bin(Mp, 0);
-        for (int64_t j = 0; j < M; ++j) bin[j] = pos[j] + (int32_t)w;
-        FZCHK(c->d_bin.ensure(Mp * 4)); FZCHK(c->d_inormpos.ensure(acc * 8));
-        FZCHK(copy_in(c, c->d_bin.p, bin.data(), Mp * 4));
-        FZCHK(copy_in(c, c->d_inormpos.p, inv.data(), acc * 8));
-    }
     c->label_mode = 1; c->label_M = M;
     return 0;
 }

@@ -194,12 +194,10 @@ struct KdeView {
     int kmode;             // KDE_HIST / KDE_DICT / KDE_GRID
     // dictionary path (pdf.py:599-620), per model (padded to Mp)
     const int32_t* pos;    // y_idx
-    const int32_t* bin;    // y_idx + w0 (single sigma class)
     const int32_t* cls;    // y_std_idx
     const double* norm;    // edge-truncated kernel mass (pdf.py:613-617) / in-window sum (pdf.py:521)
     const int64_t* widths; const int64_t* offsets; const double* kern;
     int32_t w0; int64_t koff0;            // single sigma class: width and table offset
-    const double* inormpos;               // single sigma class: 1 / norm by padded bin (pos + w0), acc_stride entries
     // direct path (pdf.py:499-502, 519-524), per model
     const double* ly; const double* lstd; const int32_t* lo; const int32_t* hi;
     const double* grid;
@@ -384,25 +382,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 // ---- single pass: likelihood + softmax statistics + candidates -> PDF -----------
-// Candidate lists: 16-B entries written with one aligned dwordx4 store -- the pair's value (chi2 in
-// the weight-space body, ln-like otherwise) and a tag, what the PDF stage needs to place it: the
-// label's padded grid bin when every label shares one kernel shape (HIST: a list walk is then one
-// memory round trip per block of entries), else the model index.  (Measured alternatives, all slower
-// on the headline: 8-B values + 2- or 4-B tags in a second array, packed 12-B dwordx3 entries.)
-#ifndef FZ_PDF_U
-#define FZ_PDF_U 4
-#endif
-struct Cand { double v; int32_t tag; int32_t pad; };
-struct CandOut {
-    Cand* ent; int64_t cap;
-    const int32_t* lbins;                      // LDS: the current tile's label bins (HIST: recorded instead of the model index) or nullptr
-    // cnt: entries already in object o's list (wave-uniform), pre: the lane's rank among this step's writers
-    __device__ __forceinline__ void put(int o, int cnt, unsigned pre, double v, int tag) const {
-        Cand e; e.v = v; e.tag = tag; e.pad = 0;
-        (ent + ((size_t)o * cap + cnt))[pre] = e;
-    }
-    __device__ __forceinline__ const Cand* list(int o) const { return ent + (size_t)o * cap; }
-};
+struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 store
 
 // Block = NW waves that stream the model set TOGETHER through double-buffered LDS
 // tiles (each tile is fetched from L2/HBM once per block, not once per wave), while
@@ -432,13 +412,12 @@ struct FusedState {
 // dim_prior; TAIL = the last, possibly partial tile (only there are lanes masked).
 template <class SRC, int TW, int DPT, bool TAIL>
 __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
-                                           int jt0, int M, int lane, double lt, const CandOut& cb,
+                                           int jt0, int M, int lane, double lt, Cand* buf, int64_t cap,
                                            FusedState<TW>& fs) {
     constexpr int OD = SRC::OBJ_DOUBLES;
 #pragma unroll 1
     for (int s = 0; s < SRC::TILE / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
-        const int jb = cb.lbins ? cb.lbins[s * 64 + lane] : j;   // what a recorded pair carries: its label's bin or its model
         typename SRC::MR m;
         src.load_model_lds(cur, s * 64 + lane, m);
         double l[TW];
@@ -465,7 +444,7 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
             if (mask) {                                                   // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (c) cb.put(o, fs.cnt[o], (unsigned)pre, l[o], jb);
+                if (c) { Cand e; e.lnl = l[o]; e.j = j; e.pad = 0; buf[(size_t)o * cap + fs.cnt[o] + pre] = e; }
                 fs.cnt[o] += __builtin_popcountll(mask);
             }
         }
@@ -503,27 +482,9 @@ __device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o, 
     ws.ref[o] = newref; ws.kref[o] = src.lp.lg_full + newref;
 }
 
-// chi2^(WP/2): integer powers by multiplication, the half by a Newton-refined v_rsq_f64
-template <int WP>
-__device__ __forceinline__ double chi2_pow(double c2) {
-    double pw = 1.0;                                         // chi2^floor(WP/2)
-#pragma unroll
-    for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? c2 : pw * c2;
-    if (WP & 1) {
-        const double cc = c2 + 1e-300;                       // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
-        const double y = __builtin_amdgcn_rsq(cc);           // ~2^-26 seed
-        double sq = cc * y;                                  // ~sqrt(cc)
-        const double r = fma(-sq, 0.5 * y, 0.5);             // Goldschmidt step -> ~1e-15
-        sq = fma(sq, r, sq);
-        if (WP == 1) pw = (c2 == 0.0) ? 0.0 : sq;            // sqrt(0 + 1e-300) must not leak a weight
-        else pw = pw * sq;                                   // chi2^k * sqrt(chi2), exactly 0 at chi2 == 0
-    }
-    return pw;
-}
-
 template <class SRC, int TW, bool TAIL>
 __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
-                                             int jt0, int M, int lane, double thrf, const CandOut& cb,
+                                             int jt0, int M, int lane, double thrf, Cand* buf, int64_t cap,
                                              WState<TW>& ws) {
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW;
@@ -531,7 +492,6 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
 #pragma unroll 1
     for (int s = 0; s < SRC::TILE / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
-        const int jb = cb.lbins ? cb.lbins[s * 64 + lane] : j;
         typename SRC::MR m;
         src.load_model_lds(cur, s * 64 + lane, m);
         double c2[TW], t[TW];
@@ -560,7 +520,19 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             const double e = exp_clamped(t[o], tb);
-            const double pw = chi2_pow<WP>(c2[o]);
+            // chi2^(WP/2): integer powers by multiplication, the half by a Newton-refined v_rsq_f64
+            double pw = 1.0;                                     // chi2^floor(WP/2)
+#pragma unroll
+            for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? c2[o] : pw * c2[o];
+            if (WP & 1) {
+                const double cc = c2[o] + 1e-300;                // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
+                const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
+                double sq = cc * y;                              // ~sqrt(cc)
+                const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
+                sq = fma(sq, r, sq);
+                if (WP == 1) pw = (c2[o] == 0.0) ? 0.0 : sq;     // sqrt(0 + 1e-300) must not leak a weight
+                else pw = pw * sq;                               // chi2^k * sqrt(chi2), exactly 0 at chi2 == 0
+            }
             w[o] = pw * e;
             if (TAIL) w[o] = (j < M) ? w[o] : 0.0;
             ws.s[o] += w[o];
@@ -573,7 +545,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
             if (mask) {                                                   // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (c) cb.put(o, ws.cnt[o], (unsigned)pre, c2[o], jb);
+                if (c) { Cand e; e.lnl = c2[o]; e.j = j; e.pad = 0; buf[(size_t)o * cap + ws.cnt[o] + pre] = e; }
                 ws.cnt[o] += __builtin_popcountll(mask);
             }
         }
@@ -619,26 +591,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     SRC src = src_;
     src.tb = stage_tabs(tabs, tid, NT);
     const FastTabs tb = src.tb;
+    Cand* buf = cand + (size_t)gw * TW * cap;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
     const double thrf = (wt_thresh > 0.0) ? wt_thresh * 0.999000499833375 : 0.0;     // exp(lt)
     const bool dp = src.lp.dim_prior != 0;
-    CandOut cb;
-    // HIST: the tiles' label bins travel through LDS next to the model tiles (a global load in the
-    // step would make every candidate store wait on vmcnt, which also counts the stores before it)
-    const int32_t* binp = (kvp->kmode == KDE_HIST) ? kvp->bin : nullptr;      // padded past the last tile
-    int32_t* bins = reinterpret_cast<int32_t*>(tabs + FZ_TABS_DOUBLES + NW * (TW * OD));   // [2][TILE]
-    constexpr int BPT = (SRC::TILE + NW * 64 - 1) / (NW * 64);
-    int32_t bstage[BPT];
-    auto bins_load = [&](int tile) {
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) { const int k = tid + q * NT; if (k < TILE) bstage[q] = binp[tile * TILE + k]; }
-    };
-    auto bins_park = [&](int b) {
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) { const int k = tid + q * NT; if (k < TILE) bins[b * TILE + k] = bstage[q]; }
-    };
-    cb.cap = cap;
-    cb.ent = cand + (size_t)gw * TW * cap;
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t g = gw + rnd * nwaves;
@@ -673,7 +629,6 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             }
         };
         double2 stage[CPT];
-        if (binp) { bins_load(0); bins_park(0); }
         if (GLDS) {
             stage_tile(0, smem);
         } else {
@@ -687,9 +642,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             const double* cur = smem + (t & 1) * TD;
             double* nxt = smem + ((t + 1) & 1) * TD;
             const bool more = t + 1 < ntiles;
-            cb.lbins = binp ? bins + (t & 1) * TILE : nullptr;
             if (more) {                                           // next tile: in flight while the current one is used
-                if (binp) bins_load(t + 1);
                 if (GLDS) stage_tile(t + 1, nxt);
                 else {
 #pragma unroll
@@ -698,19 +651,18 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             }
             if (work && WM) {
                 if constexpr (WM) {
-                    if (more) fused_tile_w<SRC, TW, false>(src, tb, cur, objs, t * TILE, M, lane, thrf, cb, ws);
-                    else fused_tile_w<SRC, TW, true>(src, tb, cur, objs, t * TILE, M, lane, thrf, cb, ws);
+                    if (more) fused_tile_w<SRC, TW, false>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    else fused_tile_w<SRC, TW, true>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
                 }
             } else if (work) {                                    // unswitched on (dim_prior, last tile)
                 if (more) {
-                    if (dp) fused_tile<SRC, TW, 1, false>(src, tb, cur, objs, t * TILE, M, lane, lt, cb, fs);
-                    else fused_tile<SRC, TW, 0, false>(src, tb, cur, objs, t * TILE, M, lane, lt, cb, fs);
+                    if (dp) fused_tile<SRC, TW, 1, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 } else {
-                    if (dp) fused_tile<SRC, TW, 1, true>(src, tb, cur, objs, t * TILE, M, lane, lt, cb, fs);
-                    else fused_tile<SRC, TW, 0, true>(src, tb, cur, objs, t * TILE, M, lane, lt, cb, fs);
+                    if (dp) fused_tile<SRC, TW, 1, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 }
             }
-            if (more && binp) bins_park((t + 1) & 1);
             if (more && !GLDS) {                                  // ... and parked in the other buffer late
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(nxt)[ch] = stage[q]; }
@@ -753,69 +705,41 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 const int n = __builtin_amdgcn_readfirstlane((int)res[o * 4 + 3]);
                 if (lane == 0 && !WM) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
                 const bool ok = (le - le == 0.0);
-                double wbest = 0.0, cbest = 0.0;                  // WM: largest weight among the candidates and its chi2 -> exact max lnl
+                double lbest = -INFINITY;                         // WM: exact max lnl, from the candidates
                 if (ok) {
                     for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
                     const double thr = wt_thresh * exp_neg(mx - le, tb);
-                    const double kfin = src.lp.lg_full + le;      // WM: w = exp(lnl - le) = chi2^(WPOW/2) exp(-chi2/2 - kfin), no log
-                    const Cand* cl = cb.list(o);
-                    // A wave walks its object's list alone: four 64-entry blocks per trip, and the next
-                    // trip's entries are requested before the current ones are used.  HIST (one kernel
-                    // shape for all labels): the entry carries its label's bin, so a trip is ONE memory
-                    // round trip and one LDS atomic per selected pair; the edge-truncation norm, a
-                    // function of the bin alone, is applied per bin afterwards.
-                    constexpr int U = FZ_PDF_U;
-                    double v[U]; int ix[U];
-                    auto fetch = [&](int c0, double (&vv)[U], int (&ii)[U]) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int k = c0 + u * 64 + lane;
-                            const int kk = k < n ? k : 0;
-                            const Cand e = cl[kk];
-                            vv[u] = e.v;
-                            ii[u] = e.tag;
-                        }
-                    };
-                    if (n > 0) fetch(0, v, ix);
+                    const Cand* cb = buf + (size_t)o * cap;
+                    // A wave walks its object's list alone, so each trip is two dependent memory
+                    // round trips (the entries, then the labels of the selected ones): four
+                    // 64-entry blocks are kept in flight per trip to overlap them.
+                    constexpr int U = 4;
                     for (int c0 = 0; c0 < n; c0 += 64 * U) {
-                        double nv[U]; int ni[U];
-                        constexpr bool PF = false;
-                        const bool more = c0 + 64 * U < n;
-                        if (PF && more) fetch(c0 + 64 * U, nv, ni);
-                        bool sel[U]; double w[U];
+                        Cand e[U]; bool in[U], sel[U]; double w[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = cb[in[u] ? k : 0]; }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            const bool in = c0 + u * 64 + lane < n;
-                            if constexpr (WM) {
-                                const double c2 = v[u];
-                                w[u] = chi2_pow<SRC::WPOW>(c2) * exp_clamped(fma(-0.5, c2, -kfin), tb);
-                                w[u] = in ? w[u] : 0.0;
-                                if (w[u] > wbest) { wbest = w[u]; cbest = c2; }
-                            } else {
-                                w[u] = exp_neg(v[u] - le, tb);
-                            }
-                            sel[u] = in && (w[u] > thr);
+                            double l = e[u].lnl;
+                            if constexpr (WM) { l = in[u] ? src.lnl_of_chi2(e[u].lnl) : -INFINITY; lbest = fmax(lbest, l); }
+                            w[u] = exp_neg(l - le, tb);
+                            sel[u] = in[u] && (w[u] > thr);
                         }
                         if (kv.kmode == KDE_HIST) {
+                            int p[U]; double nr[U];
 #pragma unroll
-                            for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[ix[u]], w[u]);
+                            for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[p[u] + kv.w0], w[u] / nr[u]);
                         } else {
 #pragma unroll
-                            for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], ix[u], lane);
+                            for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], e[u].j, lane);
                         }
-                        if (PF && more) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u) { v[u] = nv[u]; ix[u] = ni[u]; }
-                        } else if (more) fetch(c0 + 64 * U, v, ix);
                     }
-                    if (kv.kmode == KDE_HIST)
-                        for (int k = lane; k < acc_stride; k += 64) row[k] *= kv.inormpos[k];
                 }
                 if (WM) {
-                    const double wm = wave_max(wbest);
-                    const unsigned long long hit = __ballot(wbest == wm);
-                    const double cb2 = __shfl(cbest, __builtin_ctzll(hit), 64);
-                    if (lane == 0) { if (lmap) lmap[i] = (wm > 0.0 && ok) ? src.lnl_of_chi2(cb2) : lm; if (levid) levid[i] = le; }
+                    lbest = wave_max(lbest);
+                    if (lane == 0) { if (lmap) lmap[i] = (n > 0 && ok) ? lbest : lm; if (levid) levid[i] = le; }
                 }
                 kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
             }

@@ -16,7 +16,6 @@ inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
         kv.pos = c->d_pos.as<int32_t>(); kv.cls = c->d_cls.as<int32_t>();
         kv.widths = c->d_widths.as<int64_t>(); kv.offsets = c->d_offsets.as<int64_t>(); kv.kern = c->d_kern.as<double>();
         kv.w0 = c->w0; kv.koff0 = c->h_offsets[c->cls0];
-        kv.bin = c->d_bin.as<int32_t>(); kv.inormpos = c->d_inormpos.as<double>();
         kv.kmode = c->single_cls ? KDE_HIST : KDE_DICT;
         kv.acc_stride = (int)(kv.kmode == KDE_HIST ? c->G + 2 * c->w0 : c->G);
     } else {
@@ -74,11 +73,10 @@ template <class SRC, int TW, int NW, bool WM>
 int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
     const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * 32 +
-                       (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8 + (size_t)2 * SRC::TILE * 4;
+                       (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
     if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
-    const int64_t cap = M;
-    const size_t per_wave = (size_t)TW * cap * sizeof(fz::Cand);
+    const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
     auto kern = fz::k_fused<SRC, TW, NW, WM>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = 1;           // resident blocks per CU for this kernel's registers and LDS
@@ -100,7 +98,7 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
-                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), cap, lmap, levid, pdfs,
+                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
                        c->omap);
     HIPCHK(hipGetLastError());
     return 0;
