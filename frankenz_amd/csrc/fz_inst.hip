@@ -42,16 +42,23 @@ using namespace fz;
 int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, double* lnl, double* chi2,
                           int64_t* ndim, double* scale, double* serr) {
     const int64_t M = c->M;
+    // two adjacent models per thread (16-B stores) when every plane row starts 16-B aligned
+    const uintptr_t al = (uintptr_t)lnl | (uintptr_t)chi2 | (uintptr_t)ndim | (uintptr_t)scale | (uintptr_t)serr;
+    const char* e_mpt = getenv("FZ_PLANES_MPT");
+    const int MPT = (M % 2 == 0 && (al & 15) == 0 && !(e_mpt && atoi(e_mpt) == 1)) ? 2 : 1;
+    const int64_t mblocks = (M + 256 * MPT - 1) / (256 * MPT);
     // objects per block: 256 when the grid still holds >= 4 blocks per CU (+11 % at 1e5 x 1e4), else 16
-    const bool big = ((n + 255) / 256) * ((M + 255) / 256) >= 4 * (int64_t)c->cu_count;
+    const bool big = ((n + 255) / 256) * mblocks >= 4 * (int64_t)c->cu_count;
     const int TO = big ? 256 : 16;
-    dim3 grid((unsigned)((n + TO - 1) / TO), (unsigned)((M + 255) / 256));
+    dim3 grid((unsigned)((n + TO - 1) / TO), (unsigned)mblocks);
     Timer t(c, &c->tm.ms_planes, &c->tm.n_planes);
 #define FZ_CALL_PLANES(BT_, MODE_, VAR_)                                                                  \
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     using PH_ = PhotSrc<BT_, MODE_, VAR_>;                                                                \
-    auto kern = dim_prior ? (big ? k_planes<PH_, 256, 1> : k_planes<PH_, 16, 1>)                           \
-                          : (big ? k_planes<PH_, 256, 0> : k_planes<PH_, 16, 0>);                          \
+    auto kern = MPT == 2 ? (dim_prior ? (big ? k_planes<PH_, 256, 1, 2> : k_planes<PH_, 16, 1, 2>)         \
+                                      : (big ? k_planes<PH_, 256, 0, 2> : k_planes<PH_, 16, 0, 2>))        \
+                         : (dim_prior ? (big ? k_planes<PH_, 256, 1, 1> : k_planes<PH_, 16, 1, 1>)         \
+                                      : (big ? k_planes<PH_, 256, 0, 1> : k_planes<PH_, 16, 0, 1>));       \
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, ph, n, M, lnl, chi2, ndim, scale, serr);
     FZ_SWITCH(FZ_CALL_PLANES)
     HIPCHK(hipGetLastError());

@@ -146,43 +146,62 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
 };
 
 // ---- materialising fit ------------------------------------------------------
-// A thread owns one model (registers); the block walks TO objects (16 for small problems, 256
-// when that still fills the chip: fewer model loads per plane element), UNR at a time so that
-// the independent evaluations interleave; rows of the (N,M) planes are written as
-// coalesced 512-B-per-wave stores.
-template <class PH, int TO, int DPT>
+// A thread owns MPT adjacent models (registers); the block walks TO objects (16 for small
+// problems, 256 when that still fills the chip: fewer model loads per plane element), UNR at a
+// time so that the independent evaluations interleave; rows of the (N,M) planes are written as
+// coalesced streaming stores: 8 B per lane (MPT = 1: 512 B per wave-instruction) or 16 B per lane
+// (MPT = 2: 1 KB per wave-instruction; needs M even and 16-B aligned planes).  The planes are
+// never read back by this library, so the stores are non-temporal.
+typedef double fz_d2 __attribute__((ext_vector_type(2)));
+typedef long long fz_l2 __attribute__((ext_vector_type(2)));
+template <class PH, int TO, int DPT, int MPT>
 __global__ __launch_bounds__(256) void k_planes(PH ph_, int64_t N, int64_t M, double* __restrict__ lnl,
                                                 double* __restrict__ chi2, int64_t* __restrict__ ndim,
                                                 double* __restrict__ scale, double* __restrict__ serr) {
-    constexpr int UNR = 4;
+    constexpr int UNR = 4 / MPT;
     static_assert(TO % UNR == 0, "TO must be a multiple of the unroll");
     PH ph = ph_;
     ph.tb = global_tabs();
-    const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x;
-    const bool valid = j < M;
-    typename PH::MR m;
-    ph.load_model(j, m);                       // j < Mp (Mp is a multiple of 256)
+    const int64_t j = ((int64_t)blockIdx.y * 256 + threadIdx.x) * MPT;
+    const bool valid = j < M;                  // MPT = 2: M is even, so j + 1 < M as well
+    typename PH::MR m[MPT];
+#pragma unroll
+    for (int q = 0; q < MPT; ++q) {
+        const int64_t jq = j + q < ph.mv.Mp ? j + q : ph.mv.Mp - 1;     // Mp is a multiple of 256
+        ph.load_model(jq, m[q]);
+    }
     const int64_t i0 = (int64_t)blockIdx.x * TO;
     for (int o0 = 0; o0 < TO; o0 += UNR) {
         if (i0 + o0 >= N) break;
-        PairOut r[UNR];
+        PairOut r[UNR][MPT];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + o0 + u < N ? i0 + o0 + u : N - 1;
             typename PH::OR ob;
             ph.load_obj(i, ob);
-            r[u] = ph.template eval<DPT>(ob, m);
+#pragma unroll
+            for (int q = 0; q < MPT; ++q) r[u][q] = ph.template eval<DPT>(ob, m[q]);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + o0 + u;
             if (valid && i < N) {
                 const int64_t k = i * M + j;
-                if (lnl) lnl[k] = r[u].lnl;
-                if (chi2) chi2[k] = r[u].chi2;
-                if (ndim) ndim[k] = r[u].ndim;
-                if (scale) scale[k] = r[u].scale;
-                if (serr) serr[k] = sqrt(1.0 / r[u].shape);      // pdf.py:232
+                if (MPT == 1) {
+                    if (lnl) __builtin_nontemporal_store(r[u][0].lnl, &lnl[k]);
+                    if (chi2) __builtin_nontemporal_store(r[u][0].chi2, &chi2[k]);
+                    if (ndim) __builtin_nontemporal_store((int64_t)r[u][0].ndim, &ndim[k]);
+                    if (scale) __builtin_nontemporal_store(r[u][0].scale, &scale[k]);
+                    if (serr) __builtin_nontemporal_store(sqrt(1.0 / r[u][0].shape), &serr[k]);      // pdf.py:232
+                } else {
+                    const PairOut &a = r[u][0], &b = r[u][MPT - 1];
+                    if (lnl) __builtin_nontemporal_store(fz_d2{a.lnl, b.lnl}, reinterpret_cast<fz_d2*>(&lnl[k]));
+                    if (chi2) __builtin_nontemporal_store(fz_d2{a.chi2, b.chi2}, reinterpret_cast<fz_d2*>(&chi2[k]));
+                    if (ndim) __builtin_nontemporal_store(fz_l2{a.ndim, b.ndim}, reinterpret_cast<fz_l2*>(&ndim[k]));
+                    if (scale) __builtin_nontemporal_store(fz_d2{a.scale, b.scale}, reinterpret_cast<fz_d2*>(&scale[k]));
+                    if (serr) __builtin_nontemporal_store(fz_d2{sqrt(1.0 / a.shape), sqrt(1.0 / b.shape)},
+                                                          reinterpret_cast<fz_d2*>(&serr[k]));
+                }
             }
         }
     }
