@@ -116,9 +116,10 @@ def main():
     ap.add_argument("--nmodel", type=int, default=100000)
     ap.add_argument("--mode", choices=sorted(MODES), default="A")
     ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of PDF shards")
-    ap.add_argument("--workload", choices=["fit_predict", "fit", "knn", "summarize"], default="fit_predict",
+    ap.add_argument("--workload", choices=["fit_predict", "fit", "predict", "knn", "summarize"], default="fit_predict",
                     help="fit_predict: headline fused path (default). fit: materialising BruteForce.fit "
-                         "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). knn: KMCkNN "
+                         "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). predict: "
+                         "BruteForce.predict from the stored (N,M) ln-prob plane of a fit. knn: KMCkNN "
                          "search + subset PDFs (configs[3])")
     ap.add_argument("--mask-frac", type=float, default=0.0,
                     help="fraction of object bands flagged unobserved (exercises the masked kernels)")
@@ -195,9 +196,11 @@ def main():
         d_tab = torch.log_softmax(torch.randn((args.prior, M), dtype=torch.float64, device=dev, generator=gen), dim=1)
         d_rows = torch.randint(0, args.prior, (N,), dtype=torch.int64, device=dev, generator=gen)
         prior = (d_tab, args.prior, d_rows)
-    if args.workload == "fit":
+    if args.workload in ("fit", "predict"):
         d_lnl = torch.empty((N, M), dtype=torch.float64, device=dev)
-        d_chi2 = torch.empty((N, M), dtype=torch.float64, device=dev)
+        d_chi2 = torch.empty((N, M), dtype=torch.float64, device=dev) if args.workload == "fit" else None
+    if args.workload == "predict":
+        eng.fit(dX, dXe, dXm, opts, d_lnl, None, n=N)          # the stored plane predict() reads (bruteforce.py:263-264)
     if args.workload == "knn":
         from frankenz_amd import NearestNeighbors
         Kt, kk = 25, 20
@@ -225,6 +228,9 @@ def main():
             return
         if args.workload == "fit":
             eng.fit(dX, dXe, dXm, opts, d_lnl, d_chi2, n=N)
+            return
+        if args.workload == "predict":
+            eng.predict_logwt(d_lnl, ko, d_pdf, d_lm, d_le, n=N)
             return
         if args.workload == "knn":
             eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
@@ -285,6 +291,19 @@ def main():
                               "roofline": {"bound": "hbm", "kernel": "k_planes", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                            "bytes_per_eval": 16, "avg_launch_ms": ms}}))
+        elif args.workload == "predict":
+            ms = (tm["ms_stats"] + tm["ms_kde"] + tm["ms_fused"]) / args.steps
+            gbs = N * M * 8 / (ms * 1e-3) / 1e9
+            print(json.dumps({"metric": "BruteForce.predict PDFs/sec from a stored (N,M) ln-prob plane",
+                              "value": world * N * args.steps / dt, "unit": "PDFs/s",
+                              "evals_per_s": world * N * M * args.steps / dt, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "pdfs_normalised": ok, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "BruteForce.predict(logwt=fit_lnprob): %d x %d plane -> %d PDFs" % (N, M, N)},
+                              "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in ("fused", "stats", "kde", "other")},
+                              "roofline": {"bound": "hbm", "kernel": "k_stats + k_kde", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                           "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))
         else:
             print(json.dumps({"metric": "KMCkNN objects/sec (K=25 exact top-20 searches + subset PDFs)",
                               "value": world * N * args.steps / dt, "unit": "objects/s",

@@ -712,9 +712,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
             if (cdf) {
                 FZCHK(run_cdf(c, n, (int)M, M, lpl, nullptr, nullptr, 1, ko, d_pdf, d_lm, d_le));
             } else {
-                PlaneSrc ps; ps.p = lpl; ps.ld = M;
-                FZCHK(fz_launch_stats(c, ps, n, M, 0, d_lm, d_le));
-                FZCHK(fz_launch_kde(c, ps, n, M, 0, d_lm, d_le, ko, d_pdf));
+                FZCHK(fz_launch_plane_predict(c, lpl, n, M, 0, ko, d_lm, d_le, d_pdf));
             }
         } else if (cdf) {
             FZCHK(c->d_pl[0].ensure((size_t)n * M * 8));
@@ -799,9 +797,7 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
         if (!ko->use_wt_thresh) {
             if ((rc = run_cdf(c, n, (int)M, M, d_in, nullptr, nullptr, is_log ? 1 : 0, ko, d_pdf, d_lm, d_le))) break;
         } else {
-            PlaneSrc ps; ps.p = d_in; ps.ld = M;
-            if ((rc = fz_launch_stats(c, ps, n, M, linear, d_lm, d_le))) break;
-            if ((rc = fz_launch_kde(c, ps, n, M, linear, d_lm, d_le, ko, d_pdf))) break;
+            if ((rc = fz_launch_plane_predict(c, d_in, n, M, linear, ko, d_lm, d_le, d_pdf))) break;
         }
         if (!pdf_dev && (rc = copy_out(c, pdfs + i0 * G, d_pdf, (size_t)n * G * 8))) break;
         if (lmap && !lm_dev && (rc = copy_out(c, lmap + i0, d_lm, n * 8))) break;

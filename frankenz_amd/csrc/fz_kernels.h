@@ -272,11 +272,40 @@ __device__ __forceinline__ void kde_finalize(const KdeView& kv, const double* ro
     if (kv.kmode == KDE_HIST) {
         const int w2 = 2 * kv.w0;
         const double* kr = kv.kern + kv.koff0;
-        for (int t = lane; t < G; t += 64) {
-            double v = 0.0;
-            for (int h = 0; h <= w2; ++h) v = fma(row[t + h], kr[w2 - h], v);
-            out[t] = v;
-            tot += v;
+        if (w2 < 128) {
+            // the dictionary kernel (w2 + 1 taps) sits in two registers across the wave -- one coalesced
+            // load per object instead of one load per tap and output -- and tap h reaches the FMA as a
+            // scalar operand (v_readlane); the same sums in the same order as the plain loop below
+            const double ka = (lane <= w2) ? kr[lane] : 0.0;
+            const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
+            const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
+            for (int t = lane; t < G; t += 128) {
+                const bool two = t + 64 < G;
+                const double* r0 = row + t;
+                const double* r1 = row + (two ? t + 64 : t);
+                double v0 = 0.0, v1 = 0.0;
+                const int hs = w2 < 64 ? 0 : w2 - 63;              // taps w2-h >= 64 (register kb): h < hs
+                for (int h = 0; h < hs; ++h) {
+                    const int q = w2 - h - 64;
+                    const double tap = __hiloint2double(__builtin_amdgcn_readlane(kbh, q), __builtin_amdgcn_readlane(kbl, q));
+                    v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
+                }
+#pragma unroll 4
+                for (int h = hs; h <= w2; ++h) {
+                    const int q = w2 - h;
+                    const double tap = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
+                    v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
+                }
+                out[t] = v0; tot += v0;
+                if (two) { out[t + 64] = v1; tot += v1; }
+            }
+        } else {
+            for (int t = lane; t < G; t += 64) {
+                double v = 0.0;
+                for (int h = 0; h <= w2; ++h) v = fma(row[t + h], kr[w2 - h], v);
+                out[t] = v;
+                tot += v;
+            }
         }
     } else {
         for (int t = lane; t < G; t += 64) { const double v = row[t]; out[t] = v; tot += v; }
@@ -764,6 +793,154 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             }
         }
         __syncthreads();                                          // rows -> tiles again
+    }
+}
+
+// ---- single pass over a stored (N,M) ln-weight plane -> PDFs -------------------
+// BruteForce._predict (bruteforce.py:303-372) with logwt = a materialised plane, and the tail
+// of mode C.  The two-pass form (k_stats, then k_kde) reads every row twice; here a wave reads
+// its object's row ONCE (VEC = 2: 16 B per lane; VEC = 1 for rows that do not start 16-B aligned;
+// four loads per trip, the next trip's loads in flight while the current one is used), sums the
+// weights exp(l - ref) against a wave-uniform reference that is re-based (exactly: the partial
+// sums are rescaled) before any entry could leave the exponent range, tracks the per-lane best and
+// appends the entries within the weight threshold of it -- a superset of the finally selected
+// ones -- to its private list (k_fused's hand-off: ballot + mbcnt compaction, one 16-B store
+// each).  The list is then walked with the exact evidence and the exact strict threshold, as in
+// k_fused.  Waves are independent: no block barrier after the table staging.
+template <int VEC>
+struct PlaneState {
+    double ref, s, m;          // wave-uniform reference; per-lane sum of exp(l - ref) and best l
+    bool anynan;
+    int cnt;
+};
+template <int VEC, int U, bool TAIL>
+__device__ __forceinline__ void plane_load(const double* r, int jb, int M, int lane, double (&l)[U][VEC]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = jb + (u * 64 + lane) * VEC;
+        if (VEC == 2) {
+            fz_d2 v = {-INFINITY, -INFINITY};
+            if (!TAIL || j < M) v = __builtin_nontemporal_load(reinterpret_cast<const fz_d2*>(r + j));   // M is even
+            l[u][0] = v.x; l[u][VEC - 1] = v.y;
+        } else {
+            l[u][0] = (!TAIL || j < M) ? __builtin_nontemporal_load(r + j) : -INFINITY;
+        }
+    }
+}
+template <int VEC, int U, bool TAIL>
+__device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, int M, int lane, double lt,
+                                           const FastTabs& tb, Cand* buf, PlaneState<VEC>& ps) {
+    double mm = ps.m;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { mm = vmax_raw(mm, l[u][q]); ps.anynan |= (l[u][q] != l[u][q]); }   // nan never becomes the best
+    if (__any(mm - ps.ref > 500.0)) {        // rare (first trip; the best jumps by > 500): re-base on the wave-wide best
+        const double nr = wave_max(mm);
+        ps.s *= exp_neg(ps.ref - nr, tb);    // ref = -inf: s is still 0
+        ps.ref = nr;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int j = jb + (u * 64 + lane) * VEC + q;
+            const double lv = l[u][q];
+            ps.s += exp_clamped(lv - ps.ref, tb);                     // nan, -inf and far tails -> ~1e-304
+            ps.m = vmax_raw(ps.m, lv);
+            bool c = lv >= ps.m + lt;                                 // >=: lt may be absorbed at huge |lnl|; false for nan
+            if (TAIL) c = c && (j < M);
+            const unsigned long long mask = __ballot(c);
+            if (mask) {                                               // wave-uniform
+                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (c) { Cand e; e.lnl = lv; e.j = j; e.pad = 0; buf[ps.cnt + pre] = e; }
+                ps.cnt += __builtin_popcountll(mask);
+            }
+        }
+    }
+}
+
+template <int NW, int VEC>
+__global__ __launch_bounds__(NW * 64) void k_plane_fused(const double* __restrict__ plane, int64_t ld,
+                                                          const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
+                                                          int M, double wt_thresh, int normalize,
+                                                          Cand* __restrict__ cand, int64_t cap,
+                                                          double* __restrict__ lmap, double* __restrict__ levid,
+                                                          double* __restrict__ pdfs) {
+    extern __shared__ double smem[];
+    constexpr int U = 4, STEP = 64 * VEC * U;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const FastTabs tb = stage_tabs(smem, tid, NW * 64);
+    double* row = smem + FZ_TABS_DOUBLES + (size_t)wave * acc_stride;
+    __syncthreads();
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    const int64_t gw = (int64_t)blockIdx.x * NW + wave;
+    Cand* buf = cand + (size_t)gw * cap;
+    const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
+    const KdeView kv = *kvp;
+    for (int64_t i = gw; i < N; i += nwaves) {
+        const double* r = plane + i * ld;
+        PlaneState<VEC> ps;
+        ps.ref = -INFINITY; ps.s = 0.0; ps.m = -INFINITY; ps.anynan = false; ps.cnt = 0;
+        double l[U][VEC], ln[U][VEC];
+        if (STEP <= M) plane_load<VEC, U, false>(r, 0, M, lane, l); else plane_load<VEC, U, true>(r, 0, M, lane, l);
+        const bool firstnan = (lane == 0) && (l[0][0] != l[0][0]);
+        int tick = 0;
+        for (int jb = 0; jb < M; jb += STEP) {
+            const int jn = jb + STEP;
+            if (jn + STEP <= M) plane_load<VEC, U, false>(r, jn, M, lane, ln);
+            else if (jn < M) plane_load<VEC, U, true>(r, jn, M, lane, ln);
+            if (jn <= M) plane_trip<VEC, U, false>(l, jb, M, lane, lt, tb, buf, ps);
+            else plane_trip<VEC, U, true>(l, jb, M, lane, lt, tb, buf, ps);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) l[u][q] = ln[u][q];
+            // every 8 trips the lanes take the wave-wide best, so that the filter works against the
+            // best any lane has seen
+            if ((++tick & 7) == 0) ps.m = wave_max(ps.m);
+        }
+        const int cnt = ps.cnt;
+        const bool anynan = ps.anynan;
+        const double mx = wave_max(ps.m);
+        const double ss = wave_sum(ps.s);
+        const bool fn = __any(firstnan), an = __any(anynan);
+        const double lm = fn ? (double)NAN : mx;                       // builtin max: NaN only if first
+        const double le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : ps.ref + log(ss));
+        if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
+        // the entries were written by other lanes of this wave: stores drained, vector L1 invalidated
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const bool ok = (le - le == 0.0);                              // finite evidence
+        if (ok) {
+            for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
+            const double thr = wt_thresh * exp_neg(mx - le, tb);       // wt_thresh * max(wt)
+            const int n = __builtin_amdgcn_readfirstlane(cnt);
+            for (int c0 = 0; c0 < n; c0 += 64 * U) {
+                Cand e[U]; bool in[U], sel[U]; double w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = buf[in[u] ? k : 0]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    w[u] = exp_neg(e[u].lnl - le, tb);
+                    sel[u] = in[u] && (w[u] > thr);                    // strict, pdf.py:510/591
+                }
+                if (kv.kmode == KDE_HIST) {
+                    int p[U]; double nr[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[p[u] + kv.w0], w[u] / nr[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], e[u].j, lane);
+                }
+            }
+        }
+        kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
     }
 }
 

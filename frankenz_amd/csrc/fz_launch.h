@@ -67,6 +67,43 @@ int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, c
     return fz_launch_kde_tw<SRC, 1>(c, src, kv, 1, n, M, linear, lmap, levid, ko, pdfs);
 }
 
+// predict from a stored ln-weight plane: one pass (k_plane_fused) when its candidate lists fit the
+// workspace budget, else / for linear weights / FZ_PLANE_TWOPASS=1 the two-pass kernels
+inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, int64_t M, int linear,
+                                   const fz_kde_opts* ko, double* lmap, double* levid, double* pdfs) {
+    using namespace fz;
+    PlaneSrc ps; ps.p = plane; ps.ld = M;
+    KdeView kv;
+    FZCHK(fz_kde_view(c, kv));
+    constexpr int NW = 4;
+    const size_t lds = ((size_t)FZ_TABS_DOUBLES + (size_t)NW * kv.acc_stride) * 8;
+    const bool vec2 = (M % 2 == 0) && (((uintptr_t)plane & 15) == 0);
+    auto kern = vec2 ? k_plane_fused<NW, 2> : k_plane_fused<NW, 1>;
+    int64_t blocks = 0;
+    if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int bpc = 1;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, lds));
+        const int64_t need = (n + NW - 1) / NW;
+        const int64_t fit = (int64_t)(c->ws_limit / ((size_t)M * sizeof(Cand) * NW));
+        blocks = std::min<int64_t>(need, (int64_t)std::max(1, bpc) * c->cu_count);
+        if (fit < blocks) blocks = (fit >= c->cu_count) ? (fit / c->cu_count) * c->cu_count : 0;   // whole CUs or not at all
+        if (blocks > 0 && c->d_cand.ensure((size_t)blocks * NW * M * sizeof(Cand)) != 0) blocks = 0;
+    }
+    if (blocks <= 0) {
+        FZCHK(fz_launch_stats(c, ps, n, M, linear, lmap, levid));
+        return fz_launch_kde(c, ps, n, M, linear, lmap, levid, ko, pdfs);
+    }
+    FZCHK(c->d_kv.ensure(sizeof(KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, plane, M, c->d_kv.as<KdeView>(),
+                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<Cand>(), M, lmap, levid, pdfs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // single-pass kernel; returns +1 (not an error) when its candidate workspace does
 // not fit the budget and the caller should take the two-pass route
 template <class SRC, int TW, int NW, bool WM>

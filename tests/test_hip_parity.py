@@ -593,3 +593,45 @@ def test_host_pdf_pipeline_matches_the_serial_copy_out(masked, monkeypatch):
     for sl in (slice(0, 20), slice((1 << 18) - 10, (1 << 18) + 10), slice(N - 20, N)):
         rp, rlm, rle = fo.bruteforce_fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), Y, Ye, Ym, z, ze, label_dict=od)
         close(p1[sl], rp, rtol=1e-8, atol=1e-14); close(lm1[sl], rlm); close(le1[sl], rle)
+
+
+@pytest.mark.parametrize('M', [4096, 1501])                 # even: 16-B row loads; odd: rows start on 8-B boundaries
+@pytest.mark.parametrize('single_class', [True, False])
+def test_predict_from_stored_plane_single_pass(M, single_class, monkeypatch):
+    """BruteForce.predict(logwt=...) (bruteforce.py:303-372) reads each stored row once
+    (k_plane_fused); same PDFs, lmap, levid as the two-pass kernels (FZ_PLANE_TWOPASS=1) and as
+    the oracle, including rows with -inf entries, a nan (first / not first), a +inf and an all -inf row."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(4242 + M)
+    N, B = 700, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.05 * Y; Ym = np.ones((M, B))
+    z = rs.uniform(0, 6, M)
+    ze = np.full(M, 0.05) if single_class else rs.uniform(0.01, 0.1, M)
+    # ln-weights shaped like posterior rows: a few dominant entries over a long negligible tail
+    lw = -0.5 * rs.chisquare(3, size=(N, M)) * rs.choice([1.0, 30.0, 3000.0], size=(N, 1))
+    lw[5, 10:20] = -np.inf
+    lw[6, 0] = np.nan                                        # builtin max: nan only if first
+    lw[7, 77] = np.nan
+    lw[8, 3] = np.inf
+    lw[9, :] = -np.inf
+    lw[10, :] = lw[10, 0]                                    # all equal: every entry selected
+    lw[11, :] += 1e6                                         # huge offsets: the threshold offset is absorbed
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda: bf.predict(z, ze, label_dict=d, logwt=lw.copy(), return_gof=True, verbose=False)
+    with np.errstate(all='ignore'):
+        p1, (lm1, le1) = run()
+        monkeypatch.setenv('FZ_PLANE_TWOPASS', '1')
+        p2, (lm2, le2) = run()
+        monkeypatch.delenv('FZ_PLANE_TWOPASS')
+        rp, rlm, rle = fo.bruteforce_predict(lw, z, ze, label_dict=od)
+    close(lm1, lm2, rtol=0, atol=0); close(le1, le2, rtol=1e-13, atol=1e-12)
+    close(p1, p2, rtol=1e-10, atol=1e-16)
+    close(lm1, rlm, rtol=0, atol=0); close(le1, rle, rtol=1e-12, atol=1e-11)
+    close(p1, rp, rtol=1e-8, atol=1e-14)
+    # wt_thresh = 0 keeps every entry with a non-zero weight; a large threshold keeps only the best
+    for wt in (0.0, 0.5):
+        with np.errstate(all='ignore'):
+            q1 = bf.predict(z, ze, label_dict=d, logwt=lw[:40].copy(), kde_kwargs={'wt_thresh': wt}, verbose=False)
+            rq, _, _ = fo.bruteforce_predict(lw[:40], z, ze, label_dict=od, wt_thresh=wt)
+        close(q1, rq, rtol=1e-8, atol=1e-14)
