@@ -263,8 +263,10 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
     }
 }
 
-// (convolve,) normalise, write one PDF row
-__device__ __forceinline__ void kde_finalize(const KdeView& kv, const double* row, bool ok, int normalize,
+// (convolve,) normalise, write one PDF row.  With `normalize` the un-normalised values are parked
+// back in the wave's LDS row (each 128-point pass only overwrites inputs that no later pass reads)
+// and divided on their way out: the PDF goes to HBM once and is never read back.
+__device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, bool ok, int normalize,
                                              double* out, int lane) {
     const int G = (int)kv.G;
     if (!ok) { for (int t = lane; t < G; t += 64) out[t] = NAN; return; }
@@ -290,29 +292,36 @@ __device__ __forceinline__ void kde_finalize(const KdeView& kv, const double* ro
                     const double tap = __hiloint2double(__builtin_amdgcn_readlane(kbh, q), __builtin_amdgcn_readlane(kbl, q));
                     v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
                 }
-#pragma unroll 4
                 for (int h = hs; h <= w2; ++h) {
                     const int q = w2 - h;
                     const double tap = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
                     v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
                 }
-                out[t] = v0; tot += v0;
-                if (two) { out[t + 64] = v1; tot += v1; }
+                tot += v0;
+                if (two) tot += v1;
+                if (normalize) { row[t] = v0; if (two) row[t + 64] = v1; }
+                else { out[t] = v0; if (two) out[t + 64] = v1; }
             }
         } else {
+            // wide kernels: outputs go straight out (a row entry is still an input of later outputs)
             for (int t = lane; t < G; t += 64) {
                 double v = 0.0;
                 for (int h = 0; h <= w2; ++h) v = fma(row[t + h], kr[w2 - h], v);
                 out[t] = v;
                 tot += v;
             }
+            if (normalize) {
+                tot = wave_sum(tot);
+                for (int t = lane; t < G; t += 64) out[t] = out[t] / tot;
+            }
+            return;
         }
     } else {
-        for (int t = lane; t < G; t += 64) { const double v = row[t]; out[t] = v; tot += v; }
+        for (int t = lane; t < G; t += 64) { const double v = row[t]; tot += v; if (!normalize) out[t] = v; }
     }
     if (normalize) {
         tot = wave_sum(tot);
-        for (int t = lane; t < G; t += 64) out[t] = out[t] / tot;       // pdf /= pdf.sum()
+        for (int t = lane; t < G; t += 64) out[t] = row[t] / tot;       // pdf /= pdf.sum()
     }
 }
 

@@ -75,7 +75,7 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     PlaneSrc ps; ps.p = plane; ps.ld = M;
     KdeView kv;
     FZCHK(fz_kde_view(c, kv));
-    constexpr int NW = 4;
+    constexpr int NW = 4;          // (8 waves per block at 128 VGPRs measured 3-6 % slower)
     const size_t lds = ((size_t)FZ_TABS_DOUBLES + (size_t)NW * kv.acc_stride) * 8;
     const bool vec2 = (M % 2 == 0) && (((uintptr_t)plane & 15) == 0);
     auto kern = vec2 ? k_plane_fused<NW, 2> : k_plane_fused<NW, 1>;
