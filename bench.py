@@ -37,7 +37,10 @@ FLOPS_PASS = {"A": 54, "B": 60, "Ai": 54, "An": 54, "Bn": 60}  # one pass (likel
 
 MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True},
          "Ai": {"ignore_model_err": True},
-         "An": {"dim_prior": False}, "Bn": {"free_scale": True, "ignore_model_err": True, "dim_prior": False}}
+         "An": {"dim_prior": False}, "Bn": {"free_scale": True, "ignore_model_err": True, "dim_prior": False},
+         # free scale WITH model errors: the fixed-point loop of pdf.py:196-223 (iterations are data
+         # dependent, so SURVEY 8d asks for evals/s without a roofline fraction)
+         "C": {"free_scale": True}}
 
 
 def make_problem(n_obj, n_model, seed, B=5, noise=1.0):
@@ -317,12 +320,12 @@ def main():
         evals = float(world) * N * M * args.steps
         value = evals / dt
         # dominant kernel, HIP events on the library's own stream (per launch)
-        fam = max(("fused", "stats", "kde"), key=lambda k: tm["ms_" + k])
+        fam = max(("fused", "stats", "kde", "modec"), key=lambda k: tm["ms_" + k])
         ms_launch = tm["ms_" + fam] / max(tm["n_" + fam], 1)
         launches_per_step = max(tm["n_" + fam], 1) / args.steps
         evals_per_launch = N * M / launches_per_step
-        flops_eval = FLOPS_FUSED[args.mode] if fam == "fused" else FLOPS_PASS[args.mode]
-        ach = evals_per_launch * flops_eval / (ms_launch * 1e-3) / 1e12
+        flops_eval = (FLOPS_FUSED if fam == "fused" else FLOPS_PASS).get(args.mode) if fam != "modec" else None
+        ach = evals_per_launch * flops_eval / (ms_launch * 1e-3) / 1e12 if flops_eval else None
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
@@ -355,12 +358,13 @@ def main():
                                                    "the kernel is compute-bound on the vector ALU, see DESIGN.md 3.6)",
                          "kernel": "k_" + fam, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None, "traffic": traffic,
                          "flops_per_eval": flops_eval,
                          "avg_launch_ms": ms_launch,
                          "fused_frac": (N * M * args.steps * FLOPS_FUSED[args.mode]
                                         / ((tm["ms_fused"] + tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
-                                        / FP64_VALU_PEAK_TFLOPS)},
+                                        / FP64_VALU_PEAK_TFLOPS) if args.mode in FLOPS_FUSED else None,
+                         "modec_iterations_per_step": (tm["n_modec"] / args.steps - 2) if fam == "modec" else None},   # minus the two timed scopes (iteration driver, final pass)
         }
         if cpu1 is not None:
             out["cpu_baseline"] = cpu1

@@ -88,32 +88,35 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     const int64_t M = sub.nbr ? sub.W : c->M;
     const size_t pl = (size_t)n * M * 8;
     for (int k = 0; k < 4; ++k) FZCHK(c->d_mc[k].ensure(pl));
-    FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(n * 4)); FZCHK(c->d_mccnt.ensure(64));
+    FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(2 * n * 4)); FZCHK(c->d_mccnt.ensure(64));
+    if (n > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.firstnan = c->d_mcfn.as<int>();
-    st.active = c->d_mcact.as<int>(); st.nactive = c->d_mccnt.as<int>();
+    int* lists[2] = {c->d_mcact.as<int>(), c->d_mcact.as<int>() + n};        // active objects: this launch / the next
+    st.list = nullptr; st.list_next = lists[0]; st.nactive = c->d_mccnt.as<int>();
     HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
     HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
-    HIPCHK(hipMemsetAsync(st.active, 0xff, n * 4, c->stream));       // all active (non-zero)
     ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B; mc.sub = sub;
     const int64_t tiles = (M + 255) / 256;
-    const int64_t nblk = n * tiles;
-    if (nblk > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
+    if (n * tiles > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
-    hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 1);
-    int it = 0, nact = 1;
+    hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(n * tiles)), dim3(256), 0, c->stream, mc, st, n, M, 1);
+    int it = 0, nact = (int)n;        // every object takes the first iteration
     while (nact > 0) {
         if (it >= max_iter)
             return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
                             "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
         HIPCHK(hipMemsetAsync(st.nactive, 0, 4, c->stream));
-        hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)nblk), dim3(256), 0, c->stream, mc, st, n, M, 0);
-        hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, st, n, o->ltol);
+        hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(nact * tiles)), dim3(256), 0, c->stream, mc, st, nact, M, 0);
+        hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((nact + 255) / 256)), dim3(256), 0, c->stream, st, nact, o->ltol);
         HIPCHK(hipMemcpyAsync(&nact, st.nactive, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        st.list = st.list_next;                                       // survivors, in arrival order
+        st.list_next = lists[(it + 1) & 1];
         ++it;
     }
+    c->tm.n_modec += it;             // iterations of the slowest object of the chunk (+1 per timed scope: the initial pass)
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -6,7 +6,9 @@
 // The rule couples all M models of one object, so the state (scale, lnl, chi2,
 // shape) of a chunk of objects is kept in (Nc,M) planes in HBM and one kernel
 // launch advances every still-active object by one iteration; a tiny kernel then
-// applies the stop rule per object.  Objects that have stopped are frozen, which
+// applies the stop rule per object and lists the objects that go on (the next launch
+// covers only those: the slowest object of a chunk can take hundreds of iterations
+// after the rest have stopped).  Objects that have stopped are frozen, which
 // reproduces the reference's per-object iteration count exactly.  The solve keeps
 // NumPy's operation order (the library is built with -ffp-contract=off) so that the
 // iterates, and therefore the stop decision, track the reference to the last ulps.
@@ -22,8 +24,9 @@ struct ModeCState {
     double* sh;   // shape           (Nc,M)
     unsigned long long* err;   // (Nc) max |dlnl| as ordered bits
     int* firstnan;             // (Nc) |dlnl[0]| is NaN
-    int* active;               // (Nc)
-    int* nactive;              // (1)
+    const int* list;           // objects this launch advances (nullptr: all Nc), written by the last check
+    int* list_next;            // objects that go on (filled by k_modec_check)
+    int* nactive;              // (1) length of list_next
 };
 
 // Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
@@ -46,7 +49,11 @@ struct ModeC {
         ndim = MASKED ? __popc(jb) : nband;
         double var[BT], y[BT], x[BT], tm[BT];
         double inter = 0.0; shape = 0.0;
-        double slog = 0.0;
+        // sum_b log(var_b) = log(prod_b mantissa_b) + (sum_b exponent_b) ln 2: ONE table log per solve
+        // instead of B library logs (425 of the solve's ~660 instructions), to ~1e-15 absolute -- the
+        // size of the difference between two correctly working log implementations, eleven orders
+        // below ltol
+        double vprod = 1.0; int vexp = 0;
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
             y[b] = mv.y[(int64_t)b * mv.Mp + j];
@@ -56,7 +63,7 @@ struct ModeC {
             var[b] = ov.v[i * BT + b] + sye * sye;                  // xe^2 + (s*ye)^2
             inter += tm[b] * y[b] * x[b] / var[b];
             shape += tm[b] * (y[b] * y[b]) / var[b];
-            if (b < nband) slog += log(var[b]);                     // unmasked, pdf.py:193-194
+            if (b < nband) { int e; vprod *= frexp(var[b], &e); vexp += e; }    // unmasked, pdf.py:193-194
         }
         s = inter / shape;
         chi2 = 0.0;
@@ -65,6 +72,7 @@ struct ModeC {
             double d = x[b] - s * y[b];
             chi2 += tm[b] * (d * d) / var[b];
         }
+        const double slog = log_pos(vprod, global_tabs()) + (double)vexp * FZ_LN2;
         lnl = -0.5 * chi2 - 0.5 * ((double)ndim * FZ_LN2PI + slog);
     }
 };
@@ -72,9 +80,9 @@ struct ModeC {
 template <class MC>
 __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_t Nc, int64_t M, int init) {
     const int64_t tiles = (M + 255) / 256;
-    const int64_t i = blockIdx.x / tiles;
+    const int64_t slot = blockIdx.x / tiles;             // Nc = number of objects of this launch
+    const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
     const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
-    if (!init && !st.active[i]) return;                  // block-uniform
     const bool valid = j < M && (!mc.sub.nnb || j < mc.sub.nnb[i]);
     double e = 0.0;
     if (valid) {
@@ -105,14 +113,13 @@ __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_
 }
 
 static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nc) return;
-    if (!st.active[i]) return;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= Nc) return;
+    const int i = st.list ? st.list[slot] : (int)slot;
     const double e = __longlong_as_double((long long)st.err[i]);
     const bool go = !st.firstnan[i] && (e > ltol);       // `while lerr > ltol`
     st.err[i] = 0ull;
-    if (go) atomicAdd(st.nactive, 1);
-    else st.active[i] = 0;
+    if (go) st.list_next[atomicAdd(st.nactive, 1)] = i;
 }
 
 // after convergence: dim prior (pdf.py:226-229) and the output planes

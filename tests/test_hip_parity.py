@@ -635,3 +635,30 @@ def test_predict_from_stored_plane_single_pass(M, single_class, monkeypatch):
             q1 = bf.predict(z, ze, label_dict=d, logwt=lw[:40].copy(), kde_kwargs={'wt_thresh': wt}, verbose=False)
             rq, _, _ = fo.bruteforce_predict(lw[:40], z, ze, label_dict=od, wt_thresh=wt)
         close(q1, rq, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('M', [1000, 1001])                 # even: two models per thread, 16-B stores; odd: one, 8-B stores
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}])
+def test_fit_planes_store_width_does_not_change_results(M, kw, monkeypatch):
+    """BruteForce.fit (bruteforce.py:182-203): the seven planes are bit-identical whether a thread
+    owns two adjacent models (16-B non-temporal stores) or one (FZ_PLANES_MPT=1), and match the oracle."""
+    from frankenz_amd import BruteForce
+    rs = np.random.RandomState(808 + M)
+    N, B = 300, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = Y * rs.uniform(0.02, 0.08, size=(M, B)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    Xm[rs.rand(N, B) < 0.03] = 0
+    def run():
+        bf = BruteForce(Y, Ye, Ym)
+        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, track_scale=True, verbose=False)
+        return [bf.fit_lnprior, bf.fit_lnlike, bf.fit_lnprob, bf.fit_Ndim, bf.fit_chi2, bf.fit_scale, bf.fit_scale_err]
+    with np.errstate(all='ignore'):
+        a = run()
+        monkeypatch.setenv('FZ_PLANES_MPT', '1')
+        b = run()
+        monkeypatch.delenv('FZ_PLANES_MPT')
+        rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    close(a[1], rf['lnlike'], rtol=1e-9, atol=1e-9); close(a[4], rf['chi2'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(a[3], rf['Ndim'])

@@ -11,8 +11,13 @@ python3 bench.py --mode Ai --no-cpu > $O/m_bench_fit_predict_modeAi.json 2>/dev/
 python3 bench.py --mode A --mask-frac 0.02 --no-cpu > $O/m_bench_fit_predict_masked.json 2>/dev/null
 python3 bench.py --mode A --prior 64 --no-cpu > $O/m_bench_fit_predict_prior.json 2>/dev/null
 python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 > $O/m_bench_fit_planes.json 2>/dev/null
+python3 bench.py --workload predict --nobj 100000 --nmodel 10000 --no-cpu --steps 5 > $O/m_bench_predict_planes.json 2>/dev/null
+python3 bench.py --workload predict --nobj 20000 --nmodel 100000 --no-cpu --steps 5 > $O/m_bench_predict_planes_1e5_models.json 2>/dev/null
+python3 bench.py --mode C --model-err varying --nobj 20000 --nmodel 10000 --no-cpu --steps 2 > $O/m_bench_fit_predict_modeC.json 2>/dev/null
 python3 bench.py --workload knn --nobj 100000 --no-cpu > $O/m_bench_knn.json 2>/dev/null
 python3 bench.py --workload summarize --nobj 1000000 --no-cpu > $O/m_bench_summarize.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_headline -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/m_stats_headline.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_summarize -- python3 bench.py --workload summarize --nobj 1000000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_summarize.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_planes -- python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_planes.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_predict -- python3 bench.py --workload predict --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_predict.log 2>&1
 tail -c 600 $O/m_bench_fit_predict_modeA.json
