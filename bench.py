@@ -137,6 +137,13 @@ def main():
     ap.add_argument("--wt-thresh", type=float, default=1e-3, help="kde_kwargs wt_thresh (reference default 1e-3)")
     ap.add_argument("--noise-scale", type=float, default=1.0,
                     help="multiply the SDSS depths (side experiment: low-S/N objects keep far more models above wt_thresh)")
+    ap.add_argument("--kde", choices=["dict", "grid"], default="dict",
+                    help="dict: gauss_kde_dict on the 701-point grid with the 500-kernel dictionary (the reference demos; "
+                         "default).  grid: the direct gauss_kde on the same grid (pdf.py:444-526)")
+    ap.add_argument("--label-err", choices=["const", "varying"], default="const",
+                    help="const: every label carries sigma_z = 0.05 (one dictionary kernel: the histogram + one "
+                         "convolution path; every demo of the reference).  varying: sigma_z = U(0.01, 0.1) per model "
+                         "(many dictionary kernels: each selected model's window is added)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -149,6 +156,8 @@ def main():
     Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband, args.noise_scale)
     if args.model_err == "varying":
         Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
+    if args.label_err == "varying":
+        ze = np.random.RandomState(78).uniform(0.01, 0.1, size=ze.shape)
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
     cpu1 = cpuall = None
     if world == 1 and not args.no_cpu and args.workload == "fit_predict" and not args.prior:
@@ -183,7 +192,10 @@ def main():
 
     eng = Engine(local)
     eng.upload_models(Y, Ye, Ym)
-    eng.set_labels(z, ze, label_dict=pd)
+    if args.kde == "grid":
+        eng.set_labels(z, ze, label_grid=np.ascontiguousarray(pd.grid, dtype=np.float64))
+    else:
+        eng.set_labels(z, ze, label_dict=pd)
     dev = torch.device("cuda", local)
     dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
     d_pdf = torch.empty((N, G), dtype=torch.float64, device=dev)
@@ -346,7 +358,7 @@ def main():
                        "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
                        "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err,
-                       "noise_scale": args.noise_scale},
+                       "noise_scale": args.noise_scale, "kde": args.kde, "label_err": args.label_err},
             "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "
                      "and mode A runs on the mode-Ai kernels; --model-err varying times the general mode A kernels"
                      if (args.model_err == "const" and args.mode in ("A", "An")) else None),

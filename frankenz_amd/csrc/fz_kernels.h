@@ -221,6 +221,7 @@ struct KdeView {
     const double* ly; const double* lstd; const int32_t* lo; const int32_t* hi;
     const double* grid;
     int acc_stride;                       // doubles of LDS per object
+    int lane_window;                      // DICT / GRID: windows up to this many grid points are added by their own lane
 };
 // HIST: every label shares one dictionary kernel -> accumulate w/norm at the label's
 // grid index (one LDS atomic per selected model), convolve once at the end.
@@ -228,13 +229,46 @@ struct KdeView {
 enum { KDE_HIST = 0, KDE_DICT = 1, KDE_GRID = 2 };
 
 // add the selected lanes' kernels into `row`.  w: the lane's weight; jm: its model.
+// DICT / GRID: a lane adds its own model's window (LDS float atomics; up to FZ_LANE_WINDOW grid
+// points, so that 64 windows go on in parallel instead of one after the other, each behind its own
+// chain of label gathers); wider windows are added one model at a time by the whole wave.
+#define FZ_LANE_WINDOW 160               // default of KdeView::lane_window (FZ_LANE_WINDOW=n overrides, 0: always the whole wave)
 __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool sel, double w, int64_t jm,
                                             int lane) {
     if (kv.kmode == KDE_HIST) {
         if (sel) unsafeAtomicAdd(&row[kv.pos[jm] + kv.w0], w / kv.norm[jm]);
         return;
     }
-    unsigned long long mask = __ballot(sel);
+    bool wide = false;
+    if (kv.kmode == KDE_DICT) {
+        if (sel) {
+            const int p = kv.pos[jm], c = kv.cls[jm];
+            const int wd = (int)kv.widths[c];
+            const int lo = max(p - wd, 0), hi = min(p + wd + 1, (int)kv.G);
+            wide = hi - lo > kv.lane_window;
+            if (!wide) {
+                const double wn = w / kv.norm[jm];
+                const double* kr = kv.kern + kv.offsets[c] + (lo - (p - wd)) - lo;
+                for (int t = lo; t < hi; ++t) unsafeAtomicAdd(&row[t], wn * kr[t]);
+            }
+        }
+    } else {
+        if (sel) {
+            const int lo = kv.lo[jm], hi = kv.hi[jm];
+            const double nrm = kv.norm[jm];
+            wide = hi - lo > kv.lane_window;
+            if (!wide && nrm != 0.0) {                          // pdf.py:523
+                const double mu = kv.ly[jm], sd = kv.lstd[jm];
+                const double isd = 1.0 / sd;
+                const double wg = (w / nrm) / (2.5066282746310002 * sd);      // weight / (sqrt(2 pi) * std)
+                for (int t = lo; t < hi; ++t) {
+                    const double z = (kv.grid[t] - mu) * isd;
+                    unsafeAtomicAdd(&row[t], wg * exp_neg(-0.5 * (z * z)));
+                }
+            }
+        }
+    }
+    unsigned long long mask = __ballot(wide);
     while (mask) {
         const int sl = __builtin_ctzll(mask);
         mask &= mask - 1;

@@ -23,6 +23,7 @@ inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
         kv.grid = c->d_grid.as<double>();
         kv.kmode = KDE_GRID; kv.acc_stride = (int)c->G;
     }
+    kv.lane_window = getenv("FZ_LANE_WINDOW") ? atoi(getenv("FZ_LANE_WINDOW")) : FZ_LANE_WINDOW;
     if ((size_t)kv.acc_stride * 8 > 160 * 1024)
         return fail(-5, "PDF grid of %lld points needs %zu B of LDS per object (> 160 KiB)", (long long)kv.G,
                     (size_t)kv.acc_stride * 8);

@@ -662,3 +662,34 @@ def test_fit_planes_store_width_does_not_change_results(M, kw, monkeypatch):
         np.testing.assert_array_equal(u, v)
     close(a[1], rf['lnlike'], rtol=1e-9, atol=1e-9); close(a[4], rf['chi2'], rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(a[3], rf['Ndim'])
+
+
+@pytest.mark.parametrize('kde', ['dict_many_classes', 'grid'])
+def test_window_scatter_by_lane_or_by_wave(kde, monkeypatch):
+    """gauss_kde_dict with many kernel widths (pdf.py:599-620) and the direct gauss_kde
+    (pdf.py:519-524): a selected model's window is added by its own lane (up to 160 grid points) or
+    by the whole wave (FZ_LANE_WINDOW=0); same PDFs either way, and the oracle's."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(515)
+    M, N, B = 3000, 400, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.5 * rs.randn(N, B); Xe = np.full((N, B), 0.5); Xm = np.ones((N, B))
+    z = rs.uniform(-0.2, 7.2, M)                                   # some labels at / beyond the grid edges
+    ze = rs.uniform(0.01, 0.1, M); ze[::97] = 0.4                  # a few windows wider than 160 points
+    z[::131] = np.clip(z[::131], 0.1, 6.9)
+    if kde == 'grid':
+        lab = dict(label_grid=d.grid); olab = dict(label_grid=od.grid)
+        z = np.clip(z, 0.0, 7.0)
+    else:
+        lab = dict(label_dict=d); olab = dict(label_dict=od)
+        z = np.clip(z, 0.0, 7.0)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, return_gof=True,
+                                                    save_fits=False, verbose=False, **lab)
+    p0, (lm0, le0) = run()
+    monkeypatch.setenv('FZ_LANE_WINDOW', '0')
+    p1, (lm1, le1) = run()
+    monkeypatch.delenv('FZ_LANE_WINDOW')
+    close(p0, p1, rtol=1e-10, atol=1e-16); close(lm0, lm1, rtol=0, atol=0); close(le0, le1, rtol=0, atol=0)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:30].copy(), Xe[:30].copy(), Xm[:30].copy(), Y, Ye, Ym, z, ze, **olab)
+    close(p0[:30], rp, rtol=1e-8, atol=1e-14)
