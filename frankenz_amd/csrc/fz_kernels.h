@@ -268,30 +268,62 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
             }
         }
     }
-    unsigned long long mask = __ballot(wide);
-    while (mask) {
-        const int sl = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int64_t js = __shfl(jm, sl, 64);
-        const double ws = __shfl(w, sl, 64);
+    // Windows left to the whole wave, lanes along the grid (no atomics).  The labels of ALL such
+    // lanes are gathered first, lane-parallel (one round of dependent loads for the step instead of
+    // one per model); the serial loop then only moves them with v_readlane, four models per trip so
+    // that their kernel / grid loads are in flight together.  Adds of one trip go in model order:
+    // LDS operations of a wave are executed in order, so overlapping windows are safe.
+    int lo = 0, hi = 0, kidx = 0;
+    double pa = 0.0, pb = 0.0;           // DICT: weight / norm, -     GRID: weight / (norm sqrt(2 pi) std), 1 / std
+    double pc = 0.0;                     // GRID: label
+    if (wide) {
         if (kv.kmode == KDE_DICT) {
-            const int p = kv.pos[js], c = kv.cls[js];
+            const int p = kv.pos[jm], c = kv.cls[jm];
             const int wd = (int)kv.widths[c];
-            const double wn = ws / kv.norm[js];
-            const int lo = max(p - wd, 0), hi = min(p + wd + 1, (int)kv.G);
-            const double* kr = kv.kern + kv.offsets[c] + (lo - (p - wd)) - lo;
-            for (int t = lo + lane; t < hi; t += 64) row[t] = fma(wn, kr[t], row[t]);
+            lo = max(p - wd, 0); hi = min(p + wd + 1, (int)kv.G);
+            kidx = (int)kv.offsets[c] + (lo - (p - wd)) - lo;          // kernel entry of grid point t: kern[kidx + t]
+            pa = w / kv.norm[jm];
         } else {
-            const int lo = kv.lo[js], hi = kv.hi[js];
-            const double nrm = kv.norm[js];
-            if (nrm != 0.0) {                                   // pdf.py:523
-                const double mu = kv.ly[js], sd = kv.lstd[js];
-                const double wn = ws / nrm;
-                const double gn = 2.5066282746310002 * sd;      // sqrt(2 pi) * std
-                for (int t = lo + lane; t < hi; t += 64) {
-                    const double z = (kv.grid[t] - mu) / sd;
-                    row[t] = fma(wn, exp(-0.5 * (z * z)) / gn, row[t]);
-                }
+            const double nrm = kv.norm[jm], sd = kv.lstd[jm];
+            lo = kv.lo[jm]; hi = (nrm != 0.0) ? kv.hi[jm] : lo;       // pdf.py:523: kernels with zero sum are skipped
+            pa = (w / nrm) / (2.5066282746310002 * sd);
+            pb = 1.0 / sd;
+            pc = kv.ly[jm];
+        }
+    }
+    auto rl = [](double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    unsigned long long mask = __ballot(wide);
+    constexpr int UM = 4;
+    while (mask) {
+        int lo_u[UM], hi_u[UM], k_u[UM]; double a_u[UM], b_u[UM], c_u[UM], v_u[UM];
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {
+            if (mask) {
+                const int sl = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                lo_u[u] = __builtin_amdgcn_readlane(lo, sl); hi_u[u] = __builtin_amdgcn_readlane(hi, sl);
+                k_u[u] = __builtin_amdgcn_readlane(kidx, sl);
+                a_u[u] = rl(pa, sl); b_u[u] = rl(pb, sl); c_u[u] = rl(pc, sl);
+            } else { lo_u[u] = 0; hi_u[u] = 0; k_u[u] = 0; a_u[u] = b_u[u] = c_u[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {                                 // first 64 points of each window: loads together
+            const int t = lo_u[u] + lane;
+            v_u[u] = 0.0;
+            if (t < hi_u[u]) v_u[u] = (kv.kmode == KDE_DICT) ? kv.kern[k_u[u] + t] : kv.grid[t];
+        }
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {
+            const int t = lo_u[u] + lane;
+            if (t < hi_u[u]) {
+                if (kv.kmode == KDE_DICT) row[t] += a_u[u] * v_u[u];
+                else { const double z = (v_u[u] - c_u[u]) * b_u[u]; row[t] += a_u[u] * exp_neg(-0.5 * (z * z)); }
+            }
+            for (int t2 = t + 64; t2 < hi_u[u]; t2 += 64) {            // the rest of a window wider than the wave
+                if (kv.kmode == KDE_DICT) row[t2] += a_u[u] * kv.kern[k_u[u] + t2];
+                else { const double z = (kv.grid[t2] - c_u[u]) * b_u[u]; row[t2] += a_u[u] * exp_neg(-0.5 * (z * z)); }
             }
         }
     }

@@ -13,6 +13,8 @@ python3 bench.py --mode A --prior 64 --no-cpu > $O/m_bench_fit_predict_prior.jso
 python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 > $O/m_bench_fit_planes.json 2>/dev/null
 python3 bench.py --workload predict --nobj 100000 --nmodel 10000 --no-cpu --steps 5 > $O/m_bench_predict_planes.json 2>/dev/null
 python3 bench.py --workload predict --nobj 20000 --nmodel 100000 --no-cpu --steps 5 > $O/m_bench_predict_planes_1e5_models.json 2>/dev/null
+python3 bench.py --kde grid --nobj 262144 --no-cpu --steps 2 > $O/m_bench_fit_predict_grid_kde.json 2>/dev/null
+python3 bench.py --label-err varying --nobj 262144 --no-cpu --steps 2 > $O/m_bench_fit_predict_many_kernel_widths.json 2>/dev/null
 python3 bench.py --mode C --model-err varying --nobj 20000 --nmodel 10000 --no-cpu --steps 2 > $O/m_bench_fit_predict_modeC.json 2>/dev/null
 python3 bench.py --workload knn --nobj 100000 --no-cpu > $O/m_bench_knn.json 2>/dev/null
 python3 bench.py --workload summarize --nobj 1000000 --no-cpu > $O/m_bench_summarize.json 2>/dev/null
