@@ -332,12 +332,14 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
 // (convolve,) normalise, write one PDF row.  With `normalize` the un-normalised values are parked
 // back in the wave's LDS row (each 128-point pass only overwrites inputs that no later pass reads)
 // and divided on their way out: the PDF goes to HBM once and is never read back.
+// HO: the caller's instantiation only ever sees the single-kernel (histogram) form.
+template <bool HO = false>
 __device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, bool ok, int normalize,
                                              double* out, int lane) {
     const int G = (int)kv.G;
     if (!ok) { for (int t = lane; t < G; t += 64) out[t] = NAN; return; }
     double tot = 0.0;
-    if (kv.kmode == KDE_HIST) {
+    if (HO || kv.kmode == KDE_HIST) {
         const int w2 = 2 * kv.w0;
         const double* kr = kv.kern + kv.koff0;
         if (w2 < 128) {
@@ -685,7 +687,10 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
     }
 }
 
-template <class SRC, int TW, int NW, bool WM>
+// HO: instantiation for label sets with ONE dictionary kernel (histogram + one convolution: every
+// demo of the reference) -- the window-scatter code of the other KDE forms is not compiled in, so
+// that it cannot cost the hot kernel registers.
+template <class SRC, int TW, int NW, bool WM, bool HO>
 __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
                                                     int M, double wt_thresh, int normalize,
                                                     Cand* __restrict__ cand, int64_t cap,
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                             w[u] = exp_neg(l - le, tb);
                             sel[u] = in[u] && (w[u] > thr);
                         }
-                        if (kv.kmode == KDE_HIST) {
+                        if (HO || kv.kmode == KDE_HIST) {
                             int p[U]; double nr[U];
 #pragma unroll
                             for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                     lbest = wave_max(lbest);
                     if (lane == 0) { if (lmap) lmap[i] = (n > 0 && ok) ? lbest : lm; if (levid) levid[i] = le; }
                 }
-                kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
+                kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane);
             }
         }
         __syncthreads();                                          // rows -> tiles again

@@ -115,7 +115,7 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
     const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
-    auto kern = fz::k_fused<SRC, TW, NW, WM>;
+    auto kern = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, TW, NW, WM, true> : fz::k_fused<SRC, TW, NW, WM, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = 1;           // resident blocks per CU for this kernel's registers and LDS
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kern, NW * 64, lds));
