@@ -941,8 +941,8 @@ __device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, in
     }
 }
 
-template <int NW, int VEC>
-__global__ __launch_bounds__(NW * 64) void k_plane_fused(const double* __restrict__ plane, int64_t ld,
+template <int NW, int VEC, bool HO>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plane_fused(const double* __restrict__ plane, int64_t ld,
                                                           const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
                                                           int M, double wt_thresh, int normalize,
                                                           Cand* __restrict__ cand, int64_t cap,
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(NW * 64) void k_plane_fused(const double* __restric
                     w[u] = exp_neg(e[u].lnl - le, tb);
                     sel[u] = in[u] && (w[u] > thr);                    // strict, pdf.py:510/591
                 }
-                if (kv.kmode == KDE_HIST) {
+                if (HO || kv.kmode == KDE_HIST) {
                     int p[U]; double nr[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(NW * 64) void k_plane_fused(const double* __restric
                 }
             }
         }
-        kde_finalize(kv, row, ok, normalize, pdfs + i * kv.G, lane);
+        kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane);
     }
 }
 

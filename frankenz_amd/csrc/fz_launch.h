@@ -76,10 +76,12 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     PlaneSrc ps; ps.p = plane; ps.ld = M;
     KdeView kv;
     FZCHK(fz_kde_view(c, kv));
-    constexpr int NW = 4;          // (8 waves per block at 128 VGPRs measured 3-6 % slower)
+    constexpr int NW = 8;          // 8 waves share one LDS copy of the log / exp tables: two blocks per CU at G = 701
     const size_t lds = ((size_t)FZ_TABS_DOUBLES + (size_t)NW * kv.acc_stride) * 8;
     const bool vec2 = (M % 2 == 0) && (((uintptr_t)plane & 15) == 0);
-    auto kern = vec2 ? k_plane_fused<NW, 2> : k_plane_fused<NW, 1>;
+    const bool ho = kv.kmode == KDE_HIST;              // single-kernel label sets: the instantiation without the window code
+    auto kern = vec2 ? (ho ? k_plane_fused<NW, 2, true> : k_plane_fused<NW, 2, false>)
+                     : (ho ? k_plane_fused<NW, 1, true> : k_plane_fused<NW, 1, false>);
     int64_t blocks = 0;
     if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
