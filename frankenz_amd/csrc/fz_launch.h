@@ -145,13 +145,14 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 }
 
 // the weight-space kernel body is used for the chi2^(k/2) likelihoods of the exact band counts
-// (4-8 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B)
-// the ln-space body measured as fast or faster for 5 and 6 bands, so the weight-space body is
-// instantiated there only for 4 bands; from 7 bands up only mode Ai keeps it (register budget)
+// (4-8 bands unmasked, dimensionality prior on) in modes A / Ai; with the free scale (mode B) it
+// is used at 4 and 5 bands (5 bands: 100.0 vs 110.7 ms per 262 144 x 1e5 launch once the kernel
+// no longer carried the window-scatter code; at 6 bands the ln-space body is faster, 108.9 vs
+// 120.8 ms); from 7 bands up only mode Ai keeps it (register budget)
 // (FZ_NO_WSPACE=1 forces the ln-space body: A/B aid)
 template <class SRC>
 constexpr bool fz_has_wspace() {
-    return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB == 4) && (SRC::NB < 7 || SRC::LMODE == 1);
+    return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB <= 5) && (SRC::NB < 7 || SRC::LMODE == 1);
 }
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
