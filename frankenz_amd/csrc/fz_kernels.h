@@ -50,7 +50,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     // dimensionality prior is positive): the nan bookkeeping of the ln-space body is compiled out
     static constexpr bool NO_NAN = (VAR == VAR_FAST) && !PRI;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
-    static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2 && VAR == VAR_FAST) || (MODE == 0 && VAR != VAR_FAST));
+    static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2) || (MODE == 0 && VAR != VAR_FAST));   // r1_v7 sweep: masked mode B 150 vs 161 ms at (4,8)
     static constexpr bool PREF_2x8 = (BT == 7 || BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
