@@ -51,7 +51,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr bool NO_NAN = (VAR == VAR_FAST) && !PRI;
     // launch geometry preference of the ln-space body (measured, profiles/README.md)
     static constexpr bool PREF_2x16 = (BT <= 6) && ((MODE == 1) || (MODE == 2) || (MODE == 0 && VAR != VAR_FAST));   // r1_v7 sweep: masked mode B 150 vs 161 ms at (4,8)
-    static constexpr bool PREF_2x8 = (BT == 7 || BT == 8) && (MODE == 0) && (VAR == VAR_FAST);   // wide records at 128 VGPRs spill: 16 waves x 2 objects is 2-6x slower from 8 bands up
+    static constexpr bool PREF_2x8 = false;   // r1_v7 sweep: 7 / 8-band unmasked mode A now runs best at (4,8): 97 vs 105 ms, 103 vs 109 ms (was (2,8) before the lean instantiation)
     PriorView pv;                                 // read only when PRI
     struct OR : P::OR { const double* prow; };    // + the object's ln-prior row
     __device__ __forceinline__ void load_obj(int64_t i, OR& o) const {
