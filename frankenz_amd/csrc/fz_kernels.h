@@ -841,7 +841,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                     // A wave walks its object's list alone, so each trip is two dependent memory
                     // round trips (the entries, then the labels of the selected ones): four
                     // 64-entry blocks are kept in flight per trip to overlap them.
-                    constexpr int U = 4;
+                    constexpr int U = HO ? 8 : 4;
                     for (int c0 = 0; c0 < n; c0 += 64 * U) {
                         Cand e[U]; bool in[U], sel[U]; double w[U];
 #pragma unroll
