@@ -131,7 +131,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     const int BT = pick_bt(B);
     if (!BT) return fail(-5, "fz_models_upload: %d bands unsupported (max 32)", B);
     HIPCHK(hipSetDevice(c->device));
-    const int64_t Mp = (M + 255) / 256 * 256;
+    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     const size_t raw = (size_t)M * B * sizeof(double);
     FZCHK(c->d_rx.ensure(raw)); FZCHK(c->d_rxe.ensure(raw)); FZCHK(c->d_rxm.ensure(raw));
     FZCHK(copy_in(c, c->d_rx.p, y, raw)); FZCHK(copy_in(c, c->d_rxe.p, ye, raw)); FZCHK(copy_in(c, c->d_rxm.p, ym, raw));
@@ -205,7 +205,7 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     if (!c->D) return fail(-1, "fz_labels_upload_dict: upload the dictionary first");
     if (M <= 0) return fail(-1, "fz_labels_upload_dict: M <= 0");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t Mp = (M + 255) / 256 * 256;
+    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     std::vector<int64_t> hy(M), hs(M);
     if (is_device_ptr(y_idx)) {
         HIPCHK(hipMemcpy(hy.data(), y_idx, M * 8, hipMemcpyDeviceToHost));
@@ -272,7 +272,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (!c || !y || !ystd || !grid) return fail(-1, "fz_labels_upload_grid: NULL argument");
     if (M <= 0 || G <= 1) return fail(-1, "fz_labels_upload_grid: bad sizes");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t Mp = (M + 255) / 256 * 256;
+    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     FZCHK(c->d_ly.ensure(Mp * 8)); FZCHK(c->d_lstd.ensure(Mp * 8)); FZCHK(c->d_grid.ensure(G * 8));
     FZCHK(c->d_lo.ensure(Mp * 4)); FZCHK(c->d_hi.ensure(Mp * 4)); FZCHK(c->d_norm.ensure(Mp * 8));
     FZCHK(c->d_flags.ensure(64));

@@ -199,8 +199,8 @@ struct Phot {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
                 const double d = o.x[b] - m.y[b];
-                const double q = (d * d) * o.v[b];
-                chi2 = MASKED ? fma(q, tm[b], chi2) : chi2 + q;
+                if (MASKED) chi2 = fma((d * d) * o.v[b], tm[b], chi2);
+                else chi2 = fma(d * d, o.v[b], chi2);       // sub, mul, fma: three instructions per band
             }
             slogv = o.slv;
         } else {

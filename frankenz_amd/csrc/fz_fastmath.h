@@ -26,6 +26,19 @@ __device__ __forceinline__ double vmin_raw(double a, double b) {
     return r;
 }
 
+__device__ __forceinline__ float vmaxf_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a wave-uniform value the compiler cannot see is uniform (a reduction result, an LDS read): into SGPRs
+__device__ __forceinline__ double uniform_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ float uniform_f(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 // 1/v: hardware v_rcp_f64 seed + NITER Newton steps (each 2 FMAs).
 template <int NITER>
 __device__ __forceinline__ double rcp_nr(double v) {

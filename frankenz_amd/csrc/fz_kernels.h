@@ -98,15 +98,22 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     static constexpr int TILE = (NVAL > 32) ? 64 : (NVAL > 16 ? 128 : 256);
     static constexpr int RW = NVAL + ((6 - NVAL % 4) % 4);          // smallest width >= NVAL that is 2 mod 4
     static_assert(RW >= NVAL && RW % 4 == 2, "record width must be 2 mod 4 doubles (16 mod 32 bytes)");
+    // k_fused may run longer tiles (fewer block barriers) where its LDS allows: FZ_MAX_TILE models, to
+    // which the model arrays are padded (Mp).  TL = tile length actually used.
+    template <int NWAVES>
+    static constexpr int tile_len() { return (NWAVES >= 12 && RW <= 6) ? 1024 : ((NWAVES >= 8 && RW <= 10) ? 512 : TILE); }
+    template <int TL> static constexpr int tile_doubles() { return RW * TL + (P::MASKED ? TL / 2 : 0); }
     static constexpr int TILE_DOUBLES = RW * TILE + (P::MASKED ? TILE / 2 : 0);
     static constexpr int NCHUNK = TILE_DOUBLES / 2;                 // 16-byte chunks
+    template <int TL = TILE>
     __device__ __forceinline__ const double* tile_chunk_ptr(int64_t tile, int ch) const {
         const double* rec = (MODE == 0) ? P::mv.rec0 : P::mv.rec1;
-        return (ch < RW * TILE / 2) ? rec + tile * (TILE * RW) + 2 * ch
-                                    : reinterpret_cast<const double*>(P::mv.bits + tile * TILE) + 2 * (ch - RW * TILE / 2);
+        return (ch < RW * TL / 2) ? rec + tile * (TL * RW) + 2 * ch
+                                  : reinterpret_cast<const double*>(P::mv.bits + tile * TL) + 2 * (ch - RW * TL / 2);
     }
+    template <int TL = TILE>
     __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
-        return *reinterpret_cast<const double2*>(tile_chunk_ptr(tile, ch));
+        return *reinterpret_cast<const double2*>(tile_chunk_ptr<TL>(tile, ch));
     }
     // record j of the array-of-records copy, j wave-uniform: scalar loads -> SGPR operands (k_ol)
     __device__ __forceinline__ void load_model_rec(int64_t j, typename P::MR& m) const {
@@ -131,6 +138,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
         }
         m.bits = 0xffffffffu;
     }
+    template <int TL = TILE>
     __device__ __forceinline__ void load_model_lds(const double* t, int k, typename P::MR& m) const {
         const double2* r = reinterpret_cast<const double2*>(t + k * RW);
         double v[RW];
@@ -141,7 +149,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
             m.y[b] = v[b];
             if (MODE == 0) m.ye2[b] = v[BT + b];
         }
-        m.bits = P::MASKED ? reinterpret_cast<const uint32_t*>(t + RW * TILE)[k] : 0xffffffffu;
+        m.bits = P::MASKED ? reinterpret_cast<const uint32_t*>(t + RW * TL)[k] : 0xffffffffu;
     }
 };
 
@@ -333,9 +341,11 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
 // back in the wave's LDS row (each 128-point pass only overwrites inputs that no later pass reads)
 // and divided on their way out: the PDF goes to HBM once and is never read back.
 // HO: the caller's instantiation only ever sees the single-kernel (histogram) form.
+// scale: factor on the un-normalised output (the weight-space body stacks weights relative to its
+// own reference instead of the evidence; a normalised PDF does not see the difference)
 template <bool HO = false>
 __device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, bool ok, int normalize,
-                                             double* out, int lane) {
+                                             double* out, int lane, double scale = 1.0) {
     const int G = (int)kv.G;
     if (!ok) { for (int t = lane; t < G; t += 64) out[t] = NAN; return; }
     double tot = 0.0;
@@ -368,14 +378,14 @@ __device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, boo
                 tot += v0;
                 if (two) tot += v1;
                 if (normalize) { row[t] = v0; if (two) row[t + 64] = v1; }
-                else { out[t] = v0; if (two) out[t + 64] = v1; }
+                else { out[t] = v0 * scale; if (two) out[t + 64] = v1 * scale; }
             }
         } else {
             // wide kernels: outputs go straight out (a row entry is still an input of later outputs)
             for (int t = lane; t < G; t += 64) {
                 double v = 0.0;
                 for (int h = 0; h <= w2; ++h) v = fma(row[t + h], kr[w2 - h], v);
-                out[t] = v;
+                out[t] = normalize ? v : v * scale;
                 tot += v;
             }
             if (normalize) {
@@ -385,7 +395,7 @@ __device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, boo
             return;
         }
     } else {
-        for (int t = lane; t < G; t += 64) { const double v = row[t]; tot += v; if (!normalize) out[t] = v; }
+        for (int t = lane; t < G; t += 64) { const double v = row[t]; tot += v; if (!normalize) out[t] = v * scale; }
     }
     if (normalize) {
         tot = wave_sum(tot);
@@ -507,7 +517,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 // ---- single pass: likelihood + softmax statistics + candidates -> PDF -----------
-struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 store
+struct Cand { double lnl; int32_t j; int32_t pad; };      // 16 B, one dwordx4 store (lnl: the ln-like, or chi2 in the weight-space body)
+#define FZ_RES 4                                            // doubles of per-object results a wave parks in LDS
 
 // Block = NW waves that stream the model set TOGETHER through double-buffered LDS
 // tiles (each tile is fetched from L2/HBM once per block, not once per wave), while
@@ -535,16 +546,16 @@ struct FusedState {
 // updates, then candidate appends -- so that the independent per-object chains sit in
 // one basic block and their LDS / transcendental latencies overlap.  DPT pins
 // dim_prior; TAIL = the last, possibly partial tile (only there are lanes masked).
-template <class SRC, int TW, int DPT, bool TAIL>
+template <class SRC, int TW, int DPT, bool TAIL, int TL>
 __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
                                            int jt0, int M, int lane, double lt, Cand* buf, int64_t cap,
                                            FusedState<TW>& fs) {
     constexpr int OD = SRC::OBJ_DOUBLES;
 #pragma unroll 1
-    for (int s = 0; s < SRC::TILE / 64; ++s) {
+    for (int s = 0; s < TL / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
         typename SRC::MR m;
-        src.load_model_lds(cur, s * 64 + lane, m);
+        src.template load_model_lds<TL>(cur, s * 64 + lane, m);
         double l[TW];
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
@@ -588,85 +599,140 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
 }
 
 // ---- weight-space variant of the tile step (SRC::WPOW != 0, dim_prior on) ----------
-// w = exp(lnl - ref) = chi2^(WPOW/2) exp(-chi2/2 - lg - ref) is formed directly: one
-// exp, one rsqrt, no log, no selects.  `ref` (wave-uniform per object) is re-based on
-// the wave-wide best every 64 steps, and at once if a pair would overflow the range.
-// Candidates carry chi2; their exact lnl is recomputed in the PDF stage.
+// The likelihood is chi2^(WPOW/2) e^(-chi2/2) / C.  chi2 is formed in fp64 exactly as the other
+// bodies form it; what follows it -- the weight of the pair relative to a per-object reference, the
+// running sum and the candidate test -- runs in fp32 (v_exp_f32 / v_sqrt_f32: ~60 cycles per 64 pairs
+// instead of ~170 for the fp64 log-free form it replaces; tools/ubench_mix.hip has the issue rates).
+// That is sound because the hot loop only has to (a) find a SUPERSET of the models that pass the
+// weight threshold and (b) sum the weights of the rest: every candidate carries its fp64 chi2 and
+// is re-evaluated in fp64 by the PDF stage (exact ln-like, exact maximum, exact threshold, exact
+// weight in the PDF and in the evidence); only the sum over the NON-candidates (each below
+// wt_thresh of the best) enters the evidence in fp32, ~1e-7 relative on that part.
+//
+// Reference.  chi2^(k/2) e^(-chi2/2) rises up to chi2 = k and falls beyond it, so the best ln-like
+// seen is that of the smallest chi2 >= k or of the largest chi2 < k: both are tracked per lane in
+// fp64 (exactly), and a re-base takes ref = the better of the two ln-likes (two fp64 logs, rare)
+// and cref = max(its chi2, k).  The weight of a pair is
+//     w = exp(lnl - ref) = (chi2 / cref)^(k/2) * 2^(kp - (chi2 - cref) log2(e) / 2),   kp = (lnl(cref) - ref) log2(e)
+// with the difference chi2 - cref taken in fp64 BEFORE the conversion, so that the fp32 argument of
+// the exponential is small wherever the weight matters (its error is relative to the distance from
+// the best fit, not to chi2 itself).  Re-bases: every 64 steps, and at once when a pair's exponent
+// passes 60 (it beats the best by > e^40, or chi2 is ~0: an exact self match has weight 0 but a
+// chi2 far below cref) -- so no weight leaves the fp32 range and, after a re-base, the best weight
+// is 1 by construction.  Lanes whose exponent still passes 60 after the re-base (chi2 ~ 0, weight
+// <= 1) are made candidates: their clamped weight never enters a sum.
 template <int TW>
 struct WState {
-    double ref[TW], kref[TW];      // reference lnl and lg + ref (uniform)
-    double s[TW], wmax[TW];        // per-lane sum and max of w
+    double ref[TW], cref[TW];      // reference ln-like and chi2 (wave-uniform)
+    float rcr[TW], kp[TW];         // 1 / cref, (lnl(cref) - ref) log2(e)  (wave-uniform)
+    double S[TW];                  // per-lane: non-candidate weight sum (flushed from s)
+    double hi[TW], lo[TW];         // per-lane: smallest chi2 >= k, largest chi2 < k  (k = WPOW, the mode)
+    float s[TW], wmax[TW];         // per-lane: sum since the last flush, largest weight
     int cnt[TW];
     int tick;
 };
-
+template <int TW>
+__device__ __forceinline__ void w_init(WState<TW>& ws) {
+#pragma unroll
+    for (int o = 0; o < TW; ++o) {
+        ws.ref[o] = -INFINITY; ws.cref[o] = 1e300; ws.rcr[o] = 0.f; ws.kp[o] = 0.f;
+        ws.S[o] = 0.0; ws.hi[o] = 1e300; ws.lo[o] = -1.0; ws.s[o] = 0.f; ws.wmax[o] = 0.f; ws.cnt[o] = 0;
+    }
+    ws.tick = 0;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// move object o's reference to the best ln-like its wave has seen
 template <class SRC, int TW>
-__device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o, double newref) {
-    const double f = exp_neg(ws.ref[o] - newref, src.tb);        // ref = -inf: s and wmax are still 0
-    ws.s[o] *= f; ws.wmax[o] *= f;
-    ws.ref[o] = newref; ws.kref[o] = src.lp.lg_full + newref;
+__device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o) {
+    constexpr double K = (double)SRC::WPOW;
+    ws.S[o] += (double)ws.s[o]; ws.s[o] = 0.f;
+    const double H = uniform_d(wave_min(ws.hi[o])), L = uniform_d(wave_max(ws.lo[o]));
+    const double gh = src.lnl_of_chi2(H);                                  // H = 1e300 (nothing >= k yet): ~ -5e299
+    const double gl = (L > 0.0) ? src.lnl_of_chi2(L) : -INFINITY;          // nothing below the mode / chi2 == 0: weight 0
+    const double nr = uniform_d(fmax(gh, gl));
+    const double nc = (gh >= gl) ? H : K;                                  // best below the mode: centre on the mode
+    if (nr != ws.ref[o] || nc != ws.cref[o]) {                             // wave-uniform
+        const double f = uniform_d(exp_neg(ws.ref[o] - nr, src.tb));       // <= 1: the best only improves; ref = -inf: S is still 0
+        ws.S[o] *= f;
+        ws.ref[o] = nr; ws.cref[o] = nc; ws.rcr[o] = uniform_f(__builtin_amdgcn_rcpf((float)nc));
+        ws.kp[o] = uniform_f((float)((uniform_d(src.lnl_of_chi2(nc)) - nr) * 1.4426950408889634));
+    }
+    ws.wmax[o] = 1.f;                                                      // the best pair seen has weight 1 now
 }
 
-template <class SRC, int TW, bool TAIL>
+template <class SRC, int TW, bool TAIL, int TL>
 __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
-                                             int jt0, int M, int lane, double thrf, Cand* buf, int64_t cap,
+                                             int jt0, int M, int lane, float thrf, Cand* buf, int64_t cap,
                                              WState<TW>& ws) {
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW;
     static_assert(WP >= 1 && WP <= 6, "weight-space path: chi2^(1/2) ... chi2^3 (4-8 exact bands)");
+    constexpr double K = (double)WP;
 #pragma unroll 1
-    for (int s = 0; s < SRC::TILE / 64; ++s) {
+    for (int s = 0; s < TL / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
         typename SRC::MR m;
-        src.load_model_lds(cur, s * 64 + lane, m);
-        double c2[TW], t[TW];
+        src.template load_model_lds<TL>(cur, s * 64 + lane, m);
+        double c2[TW];
+        float t[TW];
         bool over = false;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             typename SRC::OR ob;
             src.load_obj_lds(objs + o * OD, ob);
             c2[o] = src.chi2_of(ob, m);
-            t[o] = fma(-0.5, c2[o], -ws.kref[o]);
-            over |= t[o] > 550.0;
+            if (TAIL) c2[o] = (j < M) ? c2[o] : 1e300;          // pad lanes: weight 0, and 1e300 never is the smallest chi2 >= k of a wave that holds a real model
+            // two-sided tracking: the value goes to its side, the other side sees a quiet NaN
+            // (high word swapped), which v_min_f64 / v_max_f64 ignore
+            const bool below = c2[o] < K;
+            const int hw = __double2hiint(c2[o]), lw = __double2loint(c2[o]);
+            ws.hi[o] = vmin_raw(ws.hi[o], __hiloint2double(below ? 0x7ff80000 : hw, lw));
+            ws.lo[o] = vmax_raw(ws.lo[o], __hiloint2double(below ? hw : 0x7ff80000, lw));
+            t[o] = fmaf((float)(c2[o] - ws.cref[o]), -0.72134752f, ws.kp[o]);      // fp64 difference, then fp32
+            over |= t[o] > 60.f;
         }
-        if (__any(over)) {                    // rare: first step of an object, or the best lnl jumps by > 550
+        bool big[TW];
+#pragma unroll
+        for (int o = 0; o < TW; ++o) big[o] = false;
+        if (__any(over)) {                    // an object's first step; a new best by > e^40; a chi2 of ~0
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
-                if (__any(t[o] > 550.0)) {    // per object, so an object's arithmetic never depends on its wave-mates
-                    double l = src.lnl_of_chi2(c2[o]);
-                    if (TAIL) l = (j < M) ? l : -INFINITY;
-                    const double cand = ws.ref[o] + log_pos(wave_max(ws.wmax[o]), tb);   // -inf while nothing was seen
-                    w_rebase(src, ws, o, fmax(cand, wave_max(l)));
-                    t[o] = fma(-0.5, c2[o], -ws.kref[o]);
+                if (__any(t[o] > 60.f)) {     // per object: an object's arithmetic never depends on its wave-mates
+                    w_rebase(src, ws, o);
+                    t[o] = fmaf((float)(c2[o] - ws.cref[o]), -0.72134752f, ws.kp[o]);
+                    big[o] = t[o] > 60.f;                     // chi2 ~ 0: true weight <= 1, exponent out of range -> candidate
+                    t[o] = fminf(t[o], 60.f);
                 }
             }
         }
-        double w[TW];
+        float w[TW];
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const double e = exp_clamped(t[o], tb);
-            // chi2^(WP/2): integer powers by multiplication, the half by a Newton-refined v_rsq_f64
-            double pw = 1.0;                                     // chi2^floor(WP/2)
+            const float r = fminf((float)c2[o] * ws.rcr[o], 1e6f);   // chi2 / cref, clamped: far tails have e == 0 (no inf * 0)
+            const float e = __builtin_amdgcn_exp2f(t[o]);
+            // (chi2 / cref)^(WP/2): integer powers by multiplication, the half by v_sqrt_f32
+            float pw = 1.f;
 #pragma unroll
-            for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? c2[o] : pw * c2[o];
-            if (WP & 1) {
-                const double cc = c2[o] + 1e-300;                // chi2 == 0 (self match): w -> 0, no 0*inf (absorbed otherwise)
-                const double y = __builtin_amdgcn_rsq(cc);       // ~2^-26 seed
-                double sq = cc * y;                              // ~sqrt(cc)
-                const double r = fma(-sq, 0.5 * y, 0.5);         // Goldschmidt step -> ~1e-15
-                sq = fma(sq, r, sq);
-                if (WP == 1) pw = (c2[o] == 0.0) ? 0.0 : sq;     // sqrt(0 + 1e-300) must not leak a weight
-                else pw = pw * sq;                               // chi2^k * sqrt(chi2), exactly 0 at chi2 == 0
-            }
-            w[o] = pw * e;
-            if (TAIL) w[o] = (j < M) ? w[o] : 0.0;
-            ws.s[o] += w[o];
-            ws.wmax[o] = vmax_raw(ws.wmax[o], w[o]);
+            for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? r : pw * r;
+            if (WP & 1) pw = (WP == 1) ? __builtin_amdgcn_sqrtf(r) : pw * __builtin_amdgcn_sqrtf(r);
+            w[o] = pw * e;                                           // chi2 == 0 (self match): exactly 0
+            if (TAIL) w[o] = (j < M) ? w[o] : 0.f;
+            ws.wmax[o] = vmaxf_raw(ws.wmax[o], w[o]);
         }
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const bool c = w[o] > ws.wmax[o] * thrf;
+            const bool c = (w[o] > ws.wmax[o] * thrf) || big[o];
             const unsigned long long mask = __ballot(c);
+            ws.s[o] += c ? 0.f : w[o];                               // candidates are summed exactly by the PDF stage
             if (mask) {                                                   // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
@@ -674,14 +740,13 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                 ws.cnt[o] += __builtin_popcountll(mask);
             }
         }
-        if ((++ws.tick & 63) == 0) {
+        ++ws.tick;
+        if ((ws.tick & 15) == 0) {
 #pragma unroll
-            for (int o = 0; o < TW; ++o) {
-                const double wm = wave_max(ws.wmax[o]);
-                if (wm > 0.0) {
-                    w_rebase(src, ws, o, ws.ref[o] + log_pos(wm, tb));
-                    ws.wmax[o] = 1.0;      // every lane now filters against the wave-wide best (w = 1 after the re-base)
-                }
+            for (int o = 0; o < TW; ++o) { ws.S[o] += (double)ws.s[o]; ws.s[o] = 0.f; }
+            if ((ws.tick & 63) == 0) {
+#pragma unroll
+                for (int o = 0; o < TW; ++o) w_rebase(src, ws, o);
             }
         }
     }
@@ -691,16 +756,20 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
 // demo of the reference) -- the window-scatter code of the other KDE forms is not compiled in, so
 // that it cannot cost the hot kernel registers.
 template <class SRC, int TW, int NW, bool WM, bool HO>
-__global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
+__global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N_,
                                                     int M, double wt_thresh, int normalize,
                                                     Cand* __restrict__ cand, int64_t cap,
                                                     double* __restrict__ lmap, double* __restrict__ levid,
-                                                    double* __restrict__ pdfs, const int* __restrict__ omap) {
+                                                    double* __restrict__ pdfs, const int* __restrict__ omap,
+                                                    int* __restrict__ redo, const int* __restrict__ ndev) {
+    // ndev: the object count lives on the device (the sweep over the objects a weight-space launch
+    // handed back: usually none, and the host never waits to find out)
+    const int64_t N = ndev ? (int64_t)*ndev : N_;
     // LDS (doubles): [2][TILE_DOUBLES] model tiles, aliased outside the model loop by
-    // the [NW][acc_stride] PDF rows | [NW][TW][4] per-object results | log/exp tables
+    // the [NW][acc_stride] PDF rows | [NW][TW][FZ_RES] per-object results | log/exp tables
     // | [NW][TW][OBJ_DOUBLES] object rows.
     extern __shared__ double smem[];
-    constexpr int TILE = SRC::TILE, TD = SRC::TILE_DOUBLES, NCH = SRC::NCHUNK, NT = NW * 64;
+    constexpr int TILE = SRC::template tile_len<NW>(), TD = SRC::template tile_doubles<TILE>(), NCH = TD / 2, NT = NW * 64;
     constexpr int CPT = (NCH + NT - 1) / NT;                      // staging chunks per thread
     constexpr int OD = SRC::OBJ_DOUBLES;
     const int tid = threadIdx.x;
@@ -713,15 +782,16 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     const int ntiles = (M + TILE - 1) / TILE;
     const int big = (((2 * TD > NW * acc_stride) ? 2 * TD : NW * acc_stride) + 1) & ~1;   // keeps what follows 16-B aligned
     double* row = smem + (size_t)wave * acc_stride;               // valid only outside the model loop
-    double* res = smem + big + wave * (TW * 4);                   // {lmap, levid, max, count} per object
-    double* tabs = smem + big + NW * TW * 4;
+    double* res = smem + big + wave * (TW * FZ_RES);              // {lmap, levid, max, count} per object (WM: {ref, sum, ~max, count})
+    double* tabs = smem + big + NW * TW * FZ_RES;
     double* objs = tabs + FZ_TABS_DOUBLES + wave * (TW * OD);
     SRC src = src_;
     src.tb = stage_tabs(tabs, tid, NT);
     const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
-    const double thrf = (wt_thresh > 0.0) ? wt_thresh * 0.999000499833375 : 0.0;     // exp(lt)
+    const float thrf = uniform_f((wt_thresh > 0.0) ? (float)(wt_thresh * 0.99) : 0.f);          // fp32 screen: a 1 % margin below the exact threshold
+    const double lthr = (wt_thresh > 0.0) ? log(wt_thresh) : -INFINITY;
     const bool dp = src.lp.dim_prior != 0;
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
@@ -730,11 +800,11 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         const int64_t i0 = work ? g * TW : 0;
         FusedState<TW> fs;
         WState<TW> ws;
-        fs.firstnan = 0; fs.anynan = 0; fs.tick = 0; ws.tick = 0;
+        fs.firstnan = 0; fs.anynan = 0; fs.tick = 0;
+        if (WM) w_init(ws);
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            if (WM) { ws.ref[o] = -INFINITY; ws.kref[o] = -INFINITY; ws.s[o] = 0.0; ws.wmax[o] = 0.0; ws.cnt[o] = 0; }
-            else { ms_init(fs.st[o]); fs.cnt[o] = 0; }
+            if (!WM) { ms_init(fs.st[o]); fs.cnt[o] = 0; }
             // omap: the launch covers a subset of the chunk's objects (N of them), listed by index
             const int64_t oslot = i0 + o < N ? i0 + o : N - 1;
             src.park_obj(omap ? (int64_t)omap[oslot] : oslot, objs + o * OD, lane);
@@ -746,13 +816,13 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         // their VGPR cap, no ds_write pass, drained by __syncthreads() (vmcnt(0)); the
         // weight-space body keeps register staging (loads issued before, parked after the
         // compute of the current tile), which measured 2-4 % faster there.
-        constexpr bool GLDS = !WM;
+        constexpr bool GLDS = true;       // (register staging measured 2-4 % faster for the old fp64 weight-space body; the fp32-tail body spills it)
         auto stage_tile = [&](int tile, double* dstbuf) {
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 const int ch = tid + q * NT;
                 if (ch < NCH)
-                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src.tile_chunk_ptr(tile, ch),
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src.template tile_chunk_ptr<TILE>(tile, ch),
                                                      (lds_void*)(dstbuf + 2 * (q * NT + wave * 64)), 16, 0, 0);
             }
         };
@@ -761,7 +831,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             stage_tile(0, smem);
         } else {
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(0, ch); }
+            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.template tile_chunk<TILE>(0, ch); }
 #pragma unroll
             for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
         }
@@ -774,21 +844,21 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 if (GLDS) stage_tile(t + 1, nxt);
                 else {
 #pragma unroll
-                    for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.tile_chunk(t + 1, ch); }
+                    for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.template tile_chunk<TILE>(t + 1, ch); }
                 }
             }
             if (work && WM) {
                 if constexpr (WM) {
-                    if (more) fused_tile_w<SRC, TW, false>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
-                    else fused_tile_w<SRC, TW, true>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    if (more) fused_tile_w<SRC, TW, false, TILE>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    else fused_tile_w<SRC, TW, true, TILE>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
                 }
             } else if (work) {                                    // unswitched on (dim_prior, last tile)
                 if (more) {
-                    if (dp) fused_tile<SRC, TW, 1, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
-                    else fused_tile<SRC, TW, 0, false>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    if (dp) fused_tile<SRC, TW, 1, false, TILE>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, false, TILE>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 } else {
-                    if (dp) fused_tile<SRC, TW, 1, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
-                    else fused_tile<SRC, TW, 0, true>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    if (dp) fused_tile<SRC, TW, 1, true, TILE>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
+                    else fused_tile<SRC, TW, 0, true, TILE>(src, tb, cur, objs, t * TILE, M, lane, lt, buf, cap, fs);
                 }
             }
             if (more && !GLDS) {                                  // ... and parked in the other buffer late
@@ -802,9 +872,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             if (WM) {
-                const double mx = ws.ref[o] + log_pos(wave_max(ws.wmax[o]), tb);      // refined below from the candidates
-                const double le = ws.ref[o] + log_pos(wave_sum(ws.s[o]), tb);
-                if (lane == 0) { res[o * 4 + 0] = mx; res[o * 4 + 1] = le; res[o * 4 + 2] = mx; res[o * 4 + 3] = (double)ws.cnt[o]; }
+                if constexpr (WM) w_rebase(src, ws, o);     // the steps since the last re-base: ref bounds EVERY ln-like from above
+                const double mxa = ws.ref[o] + log_pos((double)wave_maxf(ws.wmax[o]), tb);   // ~1e-6: only classifies candidates
+                const double sn = wave_sum(ws.S[o] + (double)ws.s[o]);
+                if (lane == 0) { res[o * FZ_RES + 0] = ws.ref[o]; res[o * FZ_RES + 1] = sn; res[o * FZ_RES + 2] = mxa; res[o * FZ_RES + 3] = (double)ws.cnt[o]; }
                 continue;
             }
             const bool fn = __any((fs.firstnan >> o) & 1u);
@@ -812,10 +883,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             const double mx = wave_max(fs.st[o].m);
             const double ss = wave_sum(fs.st[o].s * exp_neg(fs.st[o].m - mx, tb));
             if (lane == 0) {
-                res[o * 4 + 0] = fn ? (double)NAN : mx;
-                res[o * 4 + 1] = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
-                res[o * 4 + 2] = mx;
-                res[o * 4 + 3] = (double)fs.cnt[o];
+                res[o * FZ_RES + 0] = fn ? (double)NAN : mx;
+                res[o * FZ_RES + 1] = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : mx + log(ss));
+                res[o * FZ_RES + 2] = mx;
+                res[o * FZ_RES + 3] = (double)fs.cnt[o];
             }
         }
         // Tiles are dead from here on; each wave reuses its slice of the LDS as a PDF
@@ -829,28 +900,91 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             for (int o = 0; o < TW; ++o) {
                 if (i0 + o >= N) break;
                 const int64_t i = omap ? (int64_t)omap[i0 + o] : i0 + o;
-                const double lm = res[o * 4 + 0], le = res[o * 4 + 1], mx = res[o * 4 + 2];
-                const int n = __builtin_amdgcn_readfirstlane((int)res[o * 4 + 3]);
-                if (lane == 0 && !WM) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
-                const bool ok = (le - le == 0.0);
-                double lbest = -INFINITY;                         // WM: exact max lnl, from the candidates
-                if (ok) {
+                const int n = __builtin_amdgcn_readfirstlane((int)res[o * FZ_RES + 3]);
+                const Cand* cb = buf + (size_t)o * cap;
+                // A wave walks its object's list alone, so each trip is two dependent memory
+                // round trips (the entries, then the labels of the selected ones): U 64-entry
+                // blocks are kept in flight per trip to overlap them.
+                constexpr int U = (HO && !WM) ? 8 : 4;
+                if constexpr (WM) {
+                    // Candidates carry their fp64 chi2.  One walk: exact ln-like, exact maximum, the
+                    // candidates' exact share of the evidence, and the stack -- weights relative to the
+                    // loop's reference (an upper bound of every ln-like), selection against the loop's
+                    // fp32 estimate of the maximum where that is decisive (outside +-DEL of the
+                    // threshold); the few entries inside the band are settled by a second walk with
+                    // the exact maximum and evidence, by the reference's own rule (pdf.py:591).
+                    const double ref = uniform_d(res[o * FZ_RES + 0]), sn = uniform_d(res[o * FZ_RES + 1]), mxa = uniform_d(res[o * FZ_RES + 2]);
+                    constexpr double DEL = 1e-4;
                     for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
-                    const double thr = wt_thresh * exp_neg(mx - le, tb);
-                    const Cand* cb = buf + (size_t)o * cap;
-                    // A wave walks its object's list alone, so each trip is two dependent memory
-                    // round trips (the entries, then the labels of the selected ones): four
-                    // 64-entry blocks are kept in flight per trip to overlap them.
-                    constexpr int U = HO ? 8 : 4;
+                    double lbest = -INFINITY, sc = 0.0;
+                    bool anyamb = false;
                     for (int c0 = 0; c0 < n; c0 += 64 * U) {
                         Cand e[U]; bool in[U], sel[U]; double w[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = cb[in[u] ? k : 0]; }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            double l = e[u].lnl;
-                            if constexpr (WM) { l = in[u] ? src.lnl_of_chi2(e[u].lnl) : -INFINITY; lbest = fmax(lbest, l); }
-                            w[u] = exp_neg(l - le, tb);
+                            const double l = in[u] ? src.lnl_of_chi2(e[u].lnl) : -INFINITY;
+                            lbest = fmax(lbest, l);
+                            w[u] = exp_neg(l - ref, tb);
+                            sc += in[u] ? w[u] : 0.0;
+                            const double d = l - mxa;
+                            sel[u] = in[u] && (d > lthr + DEL);
+                            anyamb |= in[u] && !sel[u] && (d >= lthr - DEL);
+                        }
+                        if (HO || kv.kmode == KDE_HIST) {
+                            int p[U]; double nr[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[p[u] + kv.w0], w[u] / nr[u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) kde_scatter(kv, row, sel[u], w[u], e[u].j, lane);
+                        }
+                    }
+                    lbest = wave_max(lbest);
+                    const double stot = sn + wave_sum(sc);
+                    const double le = ref + log_pos(stot, tb);
+                    if (__any(anyamb)) {                          // wave-uniform, rare
+                        const double thr = wt_thresh * exp_neg(lbest - le, tb);          // wt_thresh * max(wt)
+                        for (int c0 = 0; c0 < n; c0 += 64) {
+                            const int k = c0 + lane;
+                            const bool in1 = k < n;
+                            const Cand e1 = cb[in1 ? k : 0];
+                            const double l = in1 ? src.lnl_of_chi2(e1.lnl) : -INFINITY;
+                            const double d = l - mxa;
+                            const bool amb = in1 && !(d > lthr + DEL) && (d >= lthr - DEL);
+                            const bool s1 = amb && (exp_neg(l - le, tb) > thr);          // strict, pdf.py:510/591
+                            const double w1 = exp_neg(l - ref, tb);
+                            if (HO || kv.kmode == KDE_HIST) {
+                                if (s1) unsafeAtomicAdd(&row[kv.pos[e1.j] + kv.w0], w1 / kv.norm[e1.j]);
+                            } else kde_scatter(kv, row, s1, w1, e1.j, lane);
+                        }
+                    }
+                    // nothing recorded / no weight at all (every chi2 so far below the mode that the fp32
+                    // weights underflow): the object is handed to the fp64 ln-space body by the host
+                    const bool ok = (le - le == 0.0) && n > 0;
+                    if (lane == 0) {
+                        if (lmap) lmap[i] = lbest;
+                        if (levid) levid[i] = le;
+                        if (!ok) redo[1 + atomicAdd(redo, 1)] = (int)i;
+                    }
+                    kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane, exp_neg(ref - le, tb));
+                } else {
+                const double lm = res[o * FZ_RES + 0], le = res[o * FZ_RES + 1], mx = res[o * FZ_RES + 2];
+                if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
+                const bool ok = (le - le == 0.0);
+                if (ok) {
+                    for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;
+                    const double thr = wt_thresh * exp_neg(mx - le, tb);
+                    for (int c0 = 0; c0 < n; c0 += 64 * U) {
+                        Cand e[U]; bool in[U], sel[U]; double w[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = cb[in[u] ? k : 0]; }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            w[u] = exp_neg(e[u].lnl - le, tb);
                             sel[u] = in[u] && (w[u] > thr);
                         }
                         if (HO || kv.kmode == KDE_HIST) {
@@ -865,11 +999,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                         }
                     }
                 }
-                if (WM) {
-                    lbest = wave_max(lbest);
-                    if (lane == 0) { if (lmap) lmap[i] = (n > 0 && ok) ? lbest : lm; if (levid) levid[i] = le; }
-                }
                 kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane);
+                }
             }
         }
         __syncthreads();                                          // rows -> tiles again

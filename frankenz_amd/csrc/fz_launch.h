@@ -112,7 +112,7 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
 template <class SRC, int TW, int NW, bool WM>
 int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    const size_t lds = std::max((size_t)2 * SRC::TILE_DOUBLES * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * 32 +
+    const size_t lds = std::max((size_t)2 * SRC::template tile_doubles<SRC::template tile_len<NW>()>() * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * FZ_RES * 8 +
                        (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
     if (lds > 160 * 1024) return 1;
     const int64_t groups = (n + TW - 1) / TW;
@@ -135,11 +135,33 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     if (c->d_cand.ensure((size_t)blocks * NW * per_wave) != 0) return 1;      // no room for the lists: two-pass route
     FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    // objects the weight-space body hands back (no candidate / no fp32 weight at all): counter + list
+    if (WM) {
+        FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
+        HIPCHK(hipMemsetAsync(c->d_redo.p, 0, sizeof(int), c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
-    Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
-                       kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
-                       c->omap);
+    {
+        Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(),
+                           kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
+                           c->omap, c->d_redo.as<int>(), (const int*)nullptr);
+        if constexpr (WM) {
+            // sweep: the fp64 ln-space body over exactly the handed-back objects (their chunk-level
+            // indices are the object map; the count stays on the device, so nothing waits for it)
+            constexpr int SW = 4;
+            auto sweep = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, 1, SW, false, true> : fz::k_fused<SRC, 1, SW, false, false>;
+            const size_t lds2 = std::max((size_t)2 * SRC::template tile_doubles<SRC::template tile_len<SW>()>() * 8, (size_t)SW * kv.acc_stride * 8) + 8 + (size_t)SW * FZ_RES * 8 +
+                                (size_t)FZ_TABS_DOUBLES * 8 + (size_t)SW * SRC::OBJ_DOUBLES * 8;
+            const int64_t sblocks = std::min<int64_t>(std::min<int64_t>(c->cu_count, (n + SW - 1) / SW), (int64_t)((size_t)blocks * NW * per_wave / ((size_t)SW * M * sizeof(fz::Cand))));
+            if (lds2 <= 160 * 1024 && sblocks >= 1) {
+                HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                hipLaunchKernelGGL(sweep, dim3((unsigned)sblocks), dim3(SW * 64), lds2, c->stream, src, c->d_kv.as<fz::KdeView>(),
+                                   kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
+                                   c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
+            }
+        }
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -241,6 +263,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 16) r = fz_launch_fused_tw<SRC, 2, 16>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            else if (tw == 2 && nw == 12) r = fz_launch_fused_tw<SRC, 2, 12>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 1 && nw == 4) r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else return fail(-1, "FZ_FUSED_CFG=%d,%d is not an instantiated configuration", tw, nw);
         }

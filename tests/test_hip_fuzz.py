@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import frankenz_oracle as fo
+from conftest import EVID
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +66,7 @@ def test_random_configuration(seed):
     assert ok.sum() >= (~undefined).sum() - np.isnan(rp).all(axis=1).sum() - 1 or N <= 3
     np.testing.assert_allclose(p[ok], rp[ok], rtol=2e-7, atol=1e-13)
     np.testing.assert_allclose(lm[ok], rlm[ok], rtol=1e-9, atol=1e-9)
-    np.testing.assert_allclose(le[ok], rle[ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(le[ok], rle[ok], **EVID)
     both_nan = np.isnan(rp).all(axis=1) & ~undefined
     assert np.isnan(p[both_nan]).all()
     # materialised planes and predict() from them
@@ -119,7 +120,7 @@ def test_random_knn_configuration(seed):
     ok = same & np.isfinite(rp).all(axis=1) & np.isfinite(p).all(axis=1)
     np.testing.assert_array_equal(nn.Nneighbors[same], rnn[same])
     np.testing.assert_allclose(p[ok], rp[ok], rtol=2e-7, atol=1e-13)
-    np.testing.assert_allclose(le[ok], rle[ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(le[ok], rle[ok], **EVID)
     fin = np.isfinite(rlnp) & same[:, None]
     np.testing.assert_allclose(nn.fit_lnprob[fin], rlnp[fin], rtol=1e-8, atol=1e-8)
 
@@ -148,6 +149,6 @@ def test_random_configuration_full_chip_geometries(seed):
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     ok = np.isfinite(rp).all(axis=1)
     np.testing.assert_allclose(p[pick][ok], rp[ok], rtol=2e-7, atol=1e-13)
-    np.testing.assert_allclose(lm[pick][ok], rlm[ok], rtol=1e-9); np.testing.assert_allclose(le[pick][ok], rle[ok], rtol=1e-9)
+    np.testing.assert_allclose(lm[pick][ok], rlm[ok], rtol=1e-9); np.testing.assert_allclose(le[pick][ok], rle[ok], **EVID)
     fin = np.isfinite(p).all(axis=1)
     assert fin.mean() > 0.99 and np.abs(p[fin].sum(axis=1) - 1).max() < 1e-9

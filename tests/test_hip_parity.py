@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import frankenz_oracle as fo
-from conftest import load_golden
+from conftest import EVID, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -188,7 +188,7 @@ def test_g7_config1_reference_mock():
                                  return_gof=True, track_scale=True, verbose=False)
     close(p[:16], g['grid_pdfs16'], rtol=1e-8, atol=1e-14)
     close(p.sum(axis=0), g['grid_pdfsum'], rtol=1e-8, atol=1e-12)
-    close(lm, g['grid_lmap'], rtol=1e-10, atol=0); close(le, g['grid_levid'], rtol=1e-10, atol=0)
+    close(lm, g['grid_lmap'], rtol=1e-10, atol=0); close(le, g['grid_levid'], **EVID)
     close(bf.fit_lnprob[:4], g['grid_lnprob_rows'], rtol=1e-9, atol=1e-9)
     close(bf.fit_lnprob.sum(axis=1), g['grid_lnprob_rowsum'], rtol=1e-9)
     close(bf.fit_scale[:4], g['grid_scale_rows'], rtol=1e-9, atol=0)
@@ -198,7 +198,7 @@ def test_g7_config1_reference_mock():
                                  verbose=False)
     close(p[:16], g['train_pdfs16'], rtol=1e-8, atol=1e-14)
     close(p.sum(axis=0), g['train_pdfsum'], rtol=1e-8, atol=1e-12)
-    close(lm, g['train_lmap'], rtol=1e-10, atol=0); close(le, g['train_levid'], rtol=1e-10, atol=0)
+    close(lm, g['train_lmap'], rtol=1e-10, atol=0); close(le, g['train_levid'], **EVID)
     close(bf.fit_lnprob[:4], g['train_lnprob_rows'], rtol=1e-9, atol=1e-9)
 
 
@@ -238,7 +238,7 @@ def test_oracle_parity_band_counts(B, kw):
     rows = ~(np.isnan(bf.fit_lnlike).any(axis=1) | np.isnan(rf['lnlike']).any(axis=1))
     assert rows.sum() >= 1 and np.isnan(rp[np.isnan(rf['lnlike']).any(axis=1)]).all()
     assert np.isnan(p[np.isnan(bf.fit_lnlike).any(axis=1)]).all()
-    close(p[rows], rp[rows], rtol=1e-8, atol=1e-13); close(lm[rows], rlm[rows]); close(le[rows], rle[rows])
+    close(p[rows], rp[rows], rtol=1e-8, atol=1e-13); close(lm[rows], rlm[rows]); close(le[rows], rle[rows], **EVID)
 
 
 @pytest.mark.parametrize('kw', [{}, {'dim_prior': False}, {'ignore_model_err': True},
@@ -270,7 +270,7 @@ def test_wild_values_take_the_ieee_variant(kw):
                                                  label_dict=od, **kw)
     close(bf.fit_chi2, rf['chi2'], rtol=1e-9, atol=1e-9)
     close(bf.fit_lnlike, rf['lnlike'], rtol=1e-9, atol=1e-9)
-    close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
     close(p, rp, rtol=1e-8, atol=1e-13)
 
 
@@ -295,7 +295,7 @@ def test_two_pass_fallback_matches_single_pass():
         finally:
             eng.set_workspace_limit(32 << 30)
     (p1, (lm1, le1)), (p2, (lm2, le2)) = out['single'], out['two']
-    close(lm1, lm2, rtol=1e-13, atol=0); close(le1, le2, rtol=1e-12, atol=1e-13)
+    close(lm1, lm2, rtol=1e-13, atol=0); close(le1, le2, **EVID)
     close(p1, p2, rtol=1e-10, atol=1e-16)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od)
@@ -320,7 +320,7 @@ def test_cdf_threshold_rule_through_the_classes(kw):
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od,
                                              kde_kwargs=kk, **kw)
     tol = dict(rtol=1e-7, atol=1e-13)
-    close(p, rp, **tol); close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    close(p, rp, **tol); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
     close(bf.predict(z, ze, label_dict=d, kde_kwargs=kk, verbose=False), rp, **tol)
     if kw.get('free_scale') and not kw.get('ignore_model_err'):
         return
@@ -356,7 +356,7 @@ def test_wide_band_sets_unmasked(B, kw):
                                  lprob_kwargs=kw, return_gof=True, verbose=False, save_fits=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
-    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, rtol=1e-9)
+    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
     bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
     rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
     close(bf.fit_lnprob, rf['lnlike'], rtol=1e-8, atol=1e-8)
@@ -390,9 +390,9 @@ def test_object_per_lane_path_matches(kw, monkeypatch):
     monkeypatch.setenv('FZ_OL', '1')
     p1, (lm1, le1) = run()
     monkeypatch.delenv('FZ_OL')
-    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:60].copy(), Xe[:60].copy(), Xm[:60].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
-    close(p1[:60], rp, rtol=1e-8, atol=1e-14); close(lm1[:60], rlm); close(le1[:60], rle)
+    close(p1[:60], rp, rtol=1e-8, atol=1e-14); close(lm1[:60], rlm); close(le1[:60], rle, **EVID)
 
 
 @pytest.mark.parametrize('N,M', [(1, 1), (3, 2), (5, 63), (2, 64), (4, 256), (3, 257), (0, 10)])
@@ -416,7 +416,7 @@ def test_tiny_and_boundary_shapes(N, M):
             continue
         rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
         ok = np.isfinite(rle)                 # M == 1 with the free scale: chi2 == 0 exactly -> -inf / nan rows
-        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(lm[ok], rlm[ok]); close(le[ok], rle[ok])
+        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(lm[ok], rlm[ok]); close(le[ok], rle[ok], **EVID)
         assert np.isnan(p[~ok]).all() == np.isnan(rp[~ok]).all()
         bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
         rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
@@ -484,9 +484,37 @@ def test_tuning_switches_do_not_change_results(env, monkeypatch):
         p1, (lm1, le1) = run()
         for k in env:
             monkeypatch.delenv(k)
-        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:30].copy(), Xe[:30].copy(), Xm[:30].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p1[:30], rp, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
+def test_exact_evidence_switch(kw, monkeypatch):
+    """The default weight-space body sums the sub-threshold weights in fp32 (EVID); FZ_NO_WSPACE=1
+    selects the all-fp64 ln-space body, whose ln-evidence is held to 1e-9 here, and the two bodies
+    give the same ln-max and PDFs.  Objects include exact self matches, a bright object (S/N 1e5)
+    and one whose only good model comes last (the reference jumps by thousands in one step)."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(909)
+    M, N, B = 2100, 260, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = np.tile(0.5 * SDSS5, (M, 1)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
+    X[:8] = Y[:8]                                           # chi2 == 0 against their own model
+    Y[-1] = 1e5 * SDSS5; X[8] = Y[-1] + SDSS5 * rs.randn(B)  # bright: every other model is off by chi2 ~ 1e10, the match is the last model
+    X[9] = Y[M // 2 + 7] + 1e-3 * SDSS5                     # a near-exact match (chi2 ~ 5e-6, far below the mode)
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    p0, (lm0, le0) = run()
+    monkeypatch.setenv('FZ_NO_WSPACE', '1')
+    p1, (lm1, le1) = run()
+    monkeypatch.delenv('FZ_NO_WSPACE')
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(le1, rle, rtol=1e-9, atol=1e-10); close(lm1, rlm, rtol=1e-9); close(p1, rp, rtol=1e-8, atol=1e-14)
+    close(le0, rle, **EVID); close(lm0, rlm, rtol=1e-9); close(p0, rp, rtol=1e-8, atol=1e-14)
+    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-12)
 
 
 @pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}, {'dim_prior': False}])
@@ -509,11 +537,11 @@ def test_masked_and_unmasked_objects_split_across_kernels(kw, monkeypatch):
     monkeypatch.setenv('FZ_NO_SPLIT', '1')
     p1, (lm1, le1) = run()
     monkeypatch.delenv('FZ_NO_SPLIT')
-    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-12); close(le0, le1, rtol=1e-12)
+    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-12); close(le0, le1, **EVID)
     masked = np.where((Xm == 0).any(axis=1))[0][:25]; full = np.where((Xm == 1).all(axis=1))[0][:25]
     pick = np.concatenate([masked, full, [17]])
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
-    close(p0[pick], rp, rtol=1e-8, atol=1e-14); close(lm0[pick], rlm); close(le0[pick], rle)
+    close(p0[pick], rp, rtol=1e-8, atol=1e-14); close(lm0[pick], rlm); close(le0[pick], rle, **EVID)
 
 
 def test_split_chunk_falls_back_as_a_whole_when_the_workspace_is_too_small():
@@ -538,7 +566,7 @@ def test_split_chunk_falls_back_as_a_whole_when_the_workspace_is_too_small():
         finally:
             eng.set_workspace_limit(32 << 30)
     (p1, (lm1, le1)), (p2, (lm2, le2)) = out['fused'], out['twopass']
-    close(p1, p2, rtol=1e-9, atol=1e-15); close(lm1, lm2, rtol=1e-12); close(le1, le2, rtol=1e-12)
+    close(p1, p2, rtol=1e-9, atol=1e-15); close(lm1, lm2, rtol=1e-12); close(le1, le2, **EVID)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_dict=od)
     close(p2[:40], rp, rtol=1e-8, atol=1e-14)
 
@@ -560,7 +588,7 @@ def test_all_zero_model_poisons_free_scale_like_the_reference():
         rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
         np.testing.assert_array_equal(np.isnan(p), np.isnan(rp)); np.testing.assert_array_equal(np.isnan(le), np.isnan(rle))
         ok = np.isfinite(rle)
-        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(le[ok], rle[ok])
+        close(p[ok], rp[ok], rtol=1e-8, atol=1e-14); close(le[ok], rle[ok], **EVID)
         if kw:
             assert np.isnan(rle).all() and np.isnan(le).all()
 
@@ -589,10 +617,10 @@ def test_host_pdf_pipeline_matches_the_serial_copy_out(masked, monkeypatch):
     if not masked:      # same launches per object either way (a split chunk's partition differs with the chunking)
         np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(lm1, lm0); np.testing.assert_array_equal(le1, le0)
     else:
-        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, rtol=1e-12)
+        close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
     for sl in (slice(0, 20), slice((1 << 18) - 10, (1 << 18) + 10), slice(N - 20, N)):
         rp, rlm, rle = fo.bruteforce_fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), Y, Ye, Ym, z, ze, label_dict=od)
-        close(p1[sl], rp, rtol=1e-8, atol=1e-14); close(lm1[sl], rlm); close(le1[sl], rle)
+        close(p1[sl], rp, rtol=1e-8, atol=1e-14); close(lm1[sl], rlm); close(le1[sl], rle, **EVID)
 
 
 @pytest.mark.parametrize('M', [4096, 1501])                 # even: 16-B row loads; odd: rows start on 8-B boundaries

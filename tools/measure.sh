@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full measurement set for profiles/ (run through gpurun; writes gpurun_out/m_*).
-#   ./tools_measure.sh
+#   ./tools/measure.sh
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O

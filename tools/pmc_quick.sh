@@ -1,26 +1,23 @@
 #!/bin/bash
-# PMC passes for the bench kernels (separate runs, kernel-trace only; never combined with
-# sys/hip traces).  Writes gpurun_out/pmc_<n>/ and prints per-kernel per-launch sums.
-#   BENCH_ARGS="--mode B" ./tools_pmc.sh
+# three SQ counter passes of the bench kernel (kernel-trace only), per-launch sums printed
+#   BENCH_ARGS="--mode B" NOBJ=262144 ./tools/pmc_quick.sh tag
 export TMPDIR=/tmp
+TAG=${1:-q}
 ARGS="--nobj ${NOBJ:-262144} --nmodel 100000 --steps 1 --warmup 1 --no-cpu ${BENCH_ARGS}"
 SETS=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
-  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
-  "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU"
-  "FETCH_SIZE"
-  "WRITE_SIZE"
-  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
-  "GRBM_GUI_ACTIVE GRBM_COUNT"
+  "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"
+  "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT"
 )
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py $ARGS > gpurun_out/pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${TAG}_$i -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_$i.log 2>&1
 done
-python3 - <<'PY'
-import csv, glob, collections
-for d in sorted(glob.glob('gpurun_out/pmc_*/')):
+python3 - "$TAG" <<'PY'
+import csv, glob, collections, sys
+tag = sys.argv[1]
+for d in sorted(glob.glob('gpurun_out/pmc_%s_*/' % tag)):
     for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
