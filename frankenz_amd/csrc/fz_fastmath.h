@@ -26,9 +26,18 @@ __device__ __forceinline__ double vmin_raw(double a, double b) {
     return r;
 }
 
+// (the s_nop is the wait state gfx950 needs between a transcendental result -- v_exp_f32, v_log_f32,
+// v_rcp_f32 ... -- and the next vector instruction that reads it: the compiler pads its own
+// instructions, it does not look inside an asm statement, and the callers feed exp2 results in)
 __device__ __forceinline__ float vmaxf_raw(float a, float b) {
     float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("s_nop 0\n\tv_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// DX9-rule multiply: 0 * anything (inf, nan included) = 0
+__device__ __forceinline__ float mul_legacy(float a, float b) {
+    float r;
+    asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 // a wave-uniform value the compiler cannot see is uniform (a reduction result, an LDS read): into SGPRs

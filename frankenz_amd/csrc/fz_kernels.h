@@ -609,24 +609,25 @@ __device__ __forceinline__ void fused_tile(const SRC& src, const FastTabs& tb, c
 // weight in the PDF and in the evidence); only the sum over the NON-candidates (each below
 // wt_thresh of the best) enters the evidence in fp32, ~1e-7 relative on that part.
 //
-// Reference.  chi2^(k/2) e^(-chi2/2) rises up to chi2 = k and falls beyond it, so the best ln-like
-// seen is that of the smallest chi2 >= k or of the largest chi2 < k: both are tracked per lane in
-// fp64 (exactly), and a re-base takes ref = the better of the two ln-likes (two fp64 logs, rare)
-// and cref = max(its chi2, k).  The weight of a pair is
-//     w = exp(lnl - ref) = (chi2 / cref)^(k/2) * 2^(kp - (chi2 - cref) log2(e) / 2),   kp = (lnl(cref) - ref) log2(e)
-// with the difference chi2 - cref taken in fp64 BEFORE the conversion, so that the fp32 argument of
-// the exponential is small wherever the weight matters (its error is relative to the distance from
-// the best fit, not to chi2 itself).  Re-bases: every 64 steps, and at once when a pair's exponent
-// passes 60 (it beats the best by > e^40, or chi2 is ~0: an exact self match has weight 0 but a
-// chi2 far below cref) -- so no weight leaves the fp32 range and, after a re-base, the best weight
-// is 1 by construction.  Lanes whose exponent still passes 60 after the re-base (chi2 ~ 0, weight
-// <= 1) are made candidates: their clamped weight never enters a sum.
+// Reference.  Each object carries (ref, cref): a reference ln-like and a reference chi2, and
+//     w = exp(lnl - ref) = 2^( (k/2) log2(chi2 / cref) - (chi2 - cref) log2(e) / 2 + kp ),   kp = (lnl(cref) - ref) log2(e)
+// holds for ANY such pair; a good pair has ref near the best ln-like (weights stay inside the fp32
+// range) and cref near the chi2 of the models that matter, because the difference chi2 - cref is
+// taken in fp64 BEFORE the conversion and the logarithm is that of a ratio near 1: the fp32
+// exponent is then small, and accurate, wherever the weight matters (its error is relative to the
+// distance from the best fit, not to chi2 itself).  ref follows the largest weight seen; cref is
+// the chi2 >= k at which the likelihood chi2^(k/2) e^(-chi2/2) takes the value e^ref (k is its
+// mode: above it every ln-like is taken once).  Re-bases: on an object's first step (from the exact
+// ln-likes of its first 64 models), every 64 steps, and at once when a pair's exponent passes 60 or
+// is not a number (a new best by > e^40; chi2 beyond the fp32 range) -- that re-base takes the exact
+// ln-likes of the current step into account, so afterwards every weight of the step is <= ~1; lanes
+// whose exponent still is out of range then are recorded as candidates on the spot (exact
+// treatment) and carry no weight in the loop.
 template <int TW>
 struct WState {
     double ref[TW], cref[TW];      // reference ln-like and chi2 (wave-uniform)
     float rcr[TW], kp[TW];         // 1 / cref, (lnl(cref) - ref) log2(e)  (wave-uniform)
     double S[TW];                  // per-lane: non-candidate weight sum (flushed from s)
-    double hi[TW], lo[TW];         // per-lane: smallest chi2 >= k, largest chi2 < k  (k = WPOW, the mode)
     float s[TW], wmax[TW];         // per-lane: sum since the last flush, largest weight
     int cnt[TW];
     int tick;
@@ -636,37 +637,41 @@ __device__ __forceinline__ void w_init(WState<TW>& ws) {
 #pragma unroll
     for (int o = 0; o < TW; ++o) {
         ws.ref[o] = -INFINITY; ws.cref[o] = 1e300; ws.rcr[o] = 0.f; ws.kp[o] = 0.f;
-        ws.S[o] = 0.0; ws.hi[o] = 1e300; ws.lo[o] = -1.0; ws.s[o] = 0.f; ws.wmax[o] = 0.f; ws.cnt[o] = 0;
+        ws.S[o] = 0.0; ws.s[o] = 0.f; ws.wmax[o] = 0.f; ws.cnt[o] = 0;
     }
     ws.tick = 0;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
 }
 __device__ __forceinline__ float wave_maxf(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// move object o's reference to the best ln-like its wave has seen
+// Move object o's reference to the best ln-like its wave has seen: the largest recorded weight,
+// or -- c2 != nullptr: the re-bases inside a step -- a model of the current step if its exact ln-like
+// beats it.
 template <class SRC, int TW>
-__device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o) {
+__device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o, const double* c2) {
     constexpr double K = (double)SRC::WPOW;
     ws.S[o] += (double)ws.s[o]; ws.s[o] = 0.f;
-    const double H = uniform_d(wave_min(ws.hi[o])), L = uniform_d(wave_max(ws.lo[o]));
-    const double gh = src.lnl_of_chi2(H);                                  // H = 1e300 (nothing >= k yet): ~ -5e299
-    const double gl = (L > 0.0) ? src.lnl_of_chi2(L) : -INFINITY;          // nothing below the mode / chi2 == 0: weight 0
-    const double nr = uniform_d(fmax(gh, gl));
-    const double nc = (gh >= gl) ? H : K;                                  // best below the mode: centre on the mode
-    if (nr != ws.ref[o] || nc != ws.cref[o]) {                             // wave-uniform
-        const double f = uniform_d(exp_neg(ws.ref[o] - nr, src.tb));       // <= 1: the best only improves; ref = -inf: S is still 0
-        ws.S[o] *= f;
-        ws.ref[o] = nr; ws.cref[o] = nc; ws.rcr[o] = uniform_f(__builtin_amdgcn_rcpf((float)nc));
+    const float wm = wave_maxf(ws.wmax[o]);
+    double nr = (wm > 0.f) ? ws.ref[o] + log_pos((double)wm, src.tb) : -INFINITY;       // ~1e-7: any reference near the best will do
+    if (c2) nr = fmax(nr, wave_max(src.lnl_of_chi2(*c2)));       // pad lanes: chi2 = 1e30 -> ~ -5e29; chi2 == 0 -> -inf
+    nr = uniform_d(nr);
+    if (nr > ws.ref[o]) {                                        // wave-uniform; false while every ln-like so far is -inf
+        const double f = uniform_d(exp_neg(ws.ref[o] - nr, src.tb));       // ref = -inf: S and wmax are still 0
+        ws.S[o] *= f; ws.wmax[o] = wm * (float)f;
+        // centre: c >= K with (K/2) ln c - c/2 - lg = nr, by the fixed point c = 2 y + K ln c (y = -(nr + lg) >= K/2 - (K/2) ln K);
+        // a rough solution is enough (kp below makes the weight formula exact for whatever centre is used)
+        const float y2 = (float)(-2.0 * (nr + src.lp.lg_full));
+        float cc = fmaxf(y2, (float)K);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) cc = fmaxf(fmaf((float)(K * 0.6931471805599453), __builtin_amdgcn_logf(cc), y2), (float)K);
+        const double nc = uniform_d((double)cc);
+        ws.ref[o] = nr; ws.cref[o] = nc; ws.rcr[o] = uniform_f(__builtin_amdgcn_rcpf(cc));
         ws.kp[o] = uniform_f((float)((uniform_d(src.lnl_of_chi2(nc)) - nr) * 1.4426950408889634));
+    } else {
+        ws.wmax[o] = wm;                                         // every lane filters against the wave-wide best
     }
-    ws.wmax[o] = 1.f;                                                      // the best pair seen has weight 1 now
 }
 
 template <class SRC, int TW, bool TAIL, int TL>
@@ -676,7 +681,15 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW;
     static_assert(WP >= 1 && WP <= 6, "weight-space path: chi2^(1/2) ... chi2^3 (4-8 exact bands)");
-    constexpr double K = (double)WP;
+    // append the lanes in `c` to object o's candidate list: ballot + mbcnt compaction, one 16-B store each
+    auto append = [&](int o, bool c, double chi2, int j) {
+        const unsigned long long mask = __ballot(c);
+        if (mask) {                                                   // wave-uniform
+            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (c) { Cand e; e.lnl = chi2; e.j = j; e.pad = 0; buf[(size_t)o * cap + ws.cnt[o] + pre] = e; }
+            ws.cnt[o] += __builtin_popcountll(mask);
+        }
+    };
 #pragma unroll 1
     for (int s = 0; s < TL / 64; ++s) {
         const int j = jt0 + s * 64 + lane;
@@ -690,55 +703,33 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
             typename SRC::OR ob;
             src.load_obj_lds(objs + o * OD, ob);
             c2[o] = src.chi2_of(ob, m);
-            if (TAIL) c2[o] = (j < M) ? c2[o] : 1e300;          // pad lanes: weight 0, and 1e300 never is the smallest chi2 >= k of a wave that holds a real model
-            // two-sided tracking: the value goes to its side, the other side sees a quiet NaN
-            // (high word swapped), which v_min_f64 / v_max_f64 ignore
-            const bool below = c2[o] < K;
-            const int hw = __double2hiint(c2[o]), lw = __double2loint(c2[o]);
-            ws.hi[o] = vmin_raw(ws.hi[o], __hiloint2double(below ? 0x7ff80000 : hw, lw));
-            ws.lo[o] = vmax_raw(ws.lo[o], __hiloint2double(below ? hw : 0x7ff80000, lw));
-            t[o] = fmaf((float)(c2[o] - ws.cref[o]), -0.72134752f, ws.kp[o]);      // fp64 difference, then fp32
-            over |= t[o] > 60.f;
+            if (TAIL) c2[o] = (j < M) ? c2[o] : 1e30;           // pad lanes: weight 0 (1e30 converts to a finite float)
+            const float dcf = (float)(c2[o] - ws.cref[o]);      // fp64 difference, then fp32
+            const float l2 = __builtin_amdgcn_logf((float)c2[o] * ws.rcr[o]);     // log2(chi2 / cref); chi2 == 0 (self match): -inf, weight 0
+            t[o] = fmaf(l2, 0.5f * WP, fmaf(dcf, -0.72134752f, ws.kp[o]));
+            over |= !(t[o] <= 60.f);                            // too large or not a number
         }
-        bool big[TW];
-#pragma unroll
-        for (int o = 0; o < TW; ++o) big[o] = false;
-        if (__any(over)) {                    // an object's first step; a new best by > e^40; a chi2 of ~0
+        if (__any(over)) {                    // an object's first step; a new best by > e^40; chi2 beyond the fp32 range
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
-                if (__any(t[o] > 60.f)) {     // per object: an object's arithmetic never depends on its wave-mates
-                    w_rebase(src, ws, o);
-                    t[o] = fmaf((float)(c2[o] - ws.cref[o]), -0.72134752f, ws.kp[o]);
-                    big[o] = t[o] > 60.f;                     // chi2 ~ 0: true weight <= 1, exponent out of range -> candidate
-                    t[o] = fminf(t[o], 60.f);
+                if (__any(!(t[o] <= 60.f))) { // per object: an object's arithmetic never depends on its wave-mates
+                    w_rebase(src, ws, o, &c2[o]);
+                    const float dcf = (float)(c2[o] - ws.cref[o]);
+                    const float l2 = __builtin_amdgcn_logf((float)c2[o] * ws.rcr[o]);
+                    t[o] = fmaf(l2, 0.5f * WP, fmaf(dcf, -0.72134752f, ws.kp[o]));
+                    const bool big = !(t[o] <= 60.f);         // still out of range (every weight of the step is <= ~1 now): exact treatment
+                    append(o, big, c2[o], j);
+                    t[o] = big ? -INFINITY : t[o];            // ... and no weight in the loop
                 }
             }
         }
-        float w[TW];
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            const float r = fminf((float)c2[o] * ws.rcr[o], 1e6f);   // chi2 / cref, clamped: far tails have e == 0 (no inf * 0)
-            const float e = __builtin_amdgcn_exp2f(t[o]);
-            // (chi2 / cref)^(WP/2): integer powers by multiplication, the half by v_sqrt_f32
-            float pw = 1.f;
-#pragma unroll
-            for (int h = 0; h < WP / 2; ++h) pw = (h == 0) ? r : pw * r;
-            if (WP & 1) pw = (WP == 1) ? __builtin_amdgcn_sqrtf(r) : pw * __builtin_amdgcn_sqrtf(r);
-            w[o] = pw * e;                                           // chi2 == 0 (self match): exactly 0
-            if (TAIL) w[o] = (j < M) ? w[o] : 0.f;
-            ws.wmax[o] = vmaxf_raw(ws.wmax[o], w[o]);
-        }
-#pragma unroll
-        for (int o = 0; o < TW; ++o) {
-            const bool c = (w[o] > ws.wmax[o] * thrf) || big[o];
-            const unsigned long long mask = __ballot(c);
-            ws.s[o] += c ? 0.f : w[o];                               // candidates are summed exactly by the PDF stage
-            if (mask) {                                                   // wave-uniform
-                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (c) { Cand e; e.lnl = c2[o]; e.j = j; e.pad = 0; buf[(size_t)o * cap + ws.cnt[o] + pre] = e; }
-                ws.cnt[o] += __builtin_popcountll(mask);
-            }
+            const float w = __builtin_amdgcn_exp2f(t[o]);
+            ws.wmax[o] = fmaxf(ws.wmax[o], w);
+            const bool c = w > ws.wmax[o] * thrf;
+            if (!c) ws.s[o] += w;                                    // candidates are summed exactly by the PDF stage
+            append(o, c, c2[o], j);
         }
         ++ws.tick;
         if ((ws.tick & 15) == 0) {
@@ -746,7 +737,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
             for (int o = 0; o < TW; ++o) { ws.S[o] += (double)ws.s[o]; ws.s[o] = 0.f; }
             if ((ws.tick & 63) == 0) {
 #pragma unroll
-                for (int o = 0; o < TW; ++o) w_rebase(src, ws, o);
+                for (int o = 0; o < TW; ++o) w_rebase(src, ws, o, nullptr);
             }
         }
     }
@@ -765,13 +756,21 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     // ndev: the object count lives on the device (the sweep over the objects a weight-space launch
     // handed back: usually none, and the host never waits to find out)
     const int64_t N = ndev ? (int64_t)*ndev : N_;
-    // LDS (doubles): [2][TILE_DOUBLES] model tiles, aliased outside the model loop by
-    // the [NW][acc_stride] PDF rows | [NW][TW][FZ_RES] per-object results | log/exp tables
-    // | [NW][TW][OBJ_DOUBLES] object rows.
-    extern __shared__ double smem[];
+    // LDS.  Static: the two model tile buffers (separate arrays: the compiler then knows that the
+    // LDS-DMA filling one does not touch the other, and does not make the reads of the current tile
+    // wait for the copy of the next), the per-object results a wave parks, the log / exp tables, the
+    // parked object rows.  Outside the model loop the tile buffers hold the waves' PDF rows (half
+    // of the waves in each); grids too long for that get dynamic LDS for the rows instead.
     constexpr int TILE = SRC::template tile_len<NW>(), TD = SRC::template tile_doubles<TILE>(), NCH = TD / 2, NT = NW * 64;
     constexpr int CPT = (NCH + NT - 1) / NT;                      // staging chunks per thread
     constexpr int OD = SRC::OBJ_DOUBLES;
+    constexpr int HW = (NW + 1) / 2;                              // waves whose rows share a tile buffer
+    __shared__ __attribute__((aligned(16))) double tileA[TD];
+    __shared__ __attribute__((aligned(16))) double tileB[TD];
+    __shared__ __attribute__((aligned(16))) double s_res[NW * TW * FZ_RES];
+    __shared__ __attribute__((aligned(16))) double s_tabs[FZ_TABS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double s_objs[NW * TW * OD];
+    extern __shared__ double smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -780,11 +779,11 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     const int64_t ngroups = (N + TW - 1) / TW;
     const int64_t nrounds = (ngroups + nwaves - 1) / nwaves;      // same for every wave: barriers stay aligned
     const int ntiles = (M + TILE - 1) / TILE;
-    const int big = (((2 * TD > NW * acc_stride) ? 2 * TD : NW * acc_stride) + 1) & ~1;   // keeps what follows 16-B aligned
-    double* row = smem + (size_t)wave * acc_stride;               // valid only outside the model loop
-    double* res = smem + big + wave * (TW * FZ_RES);              // {lmap, levid, max, count} per object (WM: {ref, sum, ~max, count})
-    double* tabs = smem + big + NW * TW * FZ_RES;
-    double* objs = tabs + FZ_TABS_DOUBLES + wave * (TW * OD);
+    double* row = (HW * acc_stride <= TD) ? ((wave < HW ? tileA : tileB) + (size_t)(wave < HW ? wave : wave - HW) * acc_stride)
+                                          : smem + (size_t)wave * acc_stride;      // valid only outside the model loop
+    double* res = s_res + wave * (TW * FZ_RES);                   // {lmap, levid, max, count} per object (WM: {ref, sum, ~max, count})
+    double* tabs = s_tabs;
+    double* objs = s_objs + wave * (TW * OD);
     SRC src = src_;
     src.tb = stage_tabs(tabs, tid, NT);
     const FastTabs tb = src.tb;
@@ -828,17 +827,16 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         };
         double2 stage[CPT];
         if (GLDS) {
-            stage_tile(0, smem);
+            stage_tile(0, tileA);
         } else {
 #pragma unroll
             for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) stage[q] = src.template tile_chunk<TILE>(0, ch); }
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(smem)[ch] = stage[q]; }
+            for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(tileA)[ch] = stage[q]; }
         }
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const double* cur = smem + (t & 1) * TD;
-            double* nxt = smem + ((t + 1) & 1) * TD;
+        // one tile: start the copy of the next one into the other buffer, evaluate this one
+        auto run_tile = [&](const double* cur, double* nxt, int t) {
             const bool more = t + 1 < ntiles;
             if (more) {                                           // next tile: in flight while the current one is used
                 if (GLDS) stage_tile(t + 1, nxt);
@@ -866,13 +864,22 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 for (int q = 0; q < CPT; ++q) { const int ch = tid + q * NT; if (ch < NCH) reinterpret_cast<double2*>(nxt)[ch] = stage[q]; }
             }
             __syncthreads();
+        };
+        if constexpr (WM) {
+            // two tiles per trip, so that each call names its buffers statically (see the LDS note above)
+            for (int t = 0; t < ntiles; t += 2) {
+                run_tile(tileA, tileB, t);
+                if (t + 1 < ntiles) run_tile(tileB, tileA, t + 1);
+            }
+        } else {
+            for (int t = 0; t < ntiles; ++t) run_tile((t & 1) ? tileB : tileA, (t & 1) ? tileA : tileB, t);
         }
         // per-object max / evidence (wave reductions), parked in LDS so that the PDF
         // stage below can be ONE loop body instead of TW inlined copies
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             if (WM) {
-                if constexpr (WM) w_rebase(src, ws, o);     // the steps since the last re-base: ref bounds EVERY ln-like from above
+                if constexpr (WM) w_rebase(src, ws, o, nullptr);     // the steps since the last re-base
                 const double mxa = ws.ref[o] + log_pos((double)wave_maxf(ws.wmax[o]), tb);   // ~1e-6: only classifies candidates
                 const double sn = wave_sum(ws.S[o] + (double)ws.s[o]);
                 if (lane == 0) { res[o * FZ_RES + 0] = ws.ref[o]; res[o * FZ_RES + 1] = sn; res[o * FZ_RES + 2] = mxa; res[o * FZ_RES + 3] = (double)ws.cnt[o]; }

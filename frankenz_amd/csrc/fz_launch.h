@@ -112,12 +112,17 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
 template <class SRC, int TW, int NW, bool WM>
 int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
-    const size_t lds = std::max((size_t)2 * SRC::template tile_doubles<SRC::template tile_len<NW>()>() * 8, (size_t)NW * kv.acc_stride * 8) + 8 + (size_t)NW * TW * FZ_RES * 8 +
-                       (size_t)FZ_TABS_DOUBLES * 8 + (size_t)NW * TW * SRC::OBJ_DOUBLES * 8;
-    if (lds > 160 * 1024) return 1;
+    // the PDF rows live inside the (static) tile buffers when half of the waves' rows fit in one, else in dynamic LDS
+    constexpr size_t TDB = (size_t)SRC::template tile_doubles<SRC::template tile_len<NW>()>();
+    const size_t lds = ((size_t)((NW + 1) / 2) * kv.acc_stride <= TDB) ? 0 : (size_t)NW * kv.acc_stride * 8;
+    auto kern = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, TW, NW, WM, true> : fz::k_fused<SRC, TW, NW, WM, false>;
+    {
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void*)kern));
+        if (fa.sharedSizeBytes + lds > 160 * 1024) return 1;
+    }
     const int64_t groups = (n + TW - 1) / TW;
     const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);
-    auto kern = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, TW, NW, WM, true> : fz::k_fused<SRC, TW, NW, WM, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks_per_cu = 1;           // resident blocks per CU for this kernel's registers and LDS
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kern, NW * 64, lds));
@@ -151,8 +156,13 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
             // indices are the object map; the count stays on the device, so nothing waits for it)
             constexpr int SW = 4;
             auto sweep = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, 1, SW, false, true> : fz::k_fused<SRC, 1, SW, false, false>;
-            const size_t lds2 = std::max((size_t)2 * SRC::template tile_doubles<SRC::template tile_len<SW>()>() * 8, (size_t)SW * kv.acc_stride * 8) + 8 + (size_t)SW * FZ_RES * 8 +
-                                (size_t)FZ_TABS_DOUBLES * 8 + (size_t)SW * SRC::OBJ_DOUBLES * 8;
+            constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
+            size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+            {
+                hipFuncAttributes fa;
+                HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
+                if (fa.sharedSizeBytes + lds2 > 160 * 1024) lds2 = (size_t)1 << 30;      // cannot run: the objects keep their (flagged) rows
+            }
             const int64_t sblocks = std::min<int64_t>(std::min<int64_t>(c->cu_count, (n + SW - 1) / SW), (int64_t)((size_t)blocks * NW * per_wave / ((size_t)SW * M * sizeof(fz::Cand))));
             if (lds2 <= 160 * 1024 && sblocks >= 1) {
                 HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -258,6 +268,9 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             // unmasked mode A and masked mode B, which want the 256-VGPR budget of 8 waves x 4;
             // wider records spill at 128 VGPRs (PREF_2x16 / PREF_2x8 in PhotSrc)
             if (tw == 4 && (fz_use_wspace(src) || SRC::PREF_2x16)) { tw = 2; nw = 16; }
+            // weight-space body with wide records (general mode A: y and ye^2; 7 and 8 bands): 16 waves leave
+            // 128 VGPRs, and the body then spills inside the model loop (3-4x slower); 12 waves (168 VGPRs) do not
+            if (tw == 2 && nw == 16 && fz_use_wspace(src) && (SRC::LMODE == 0 || SRC::NB >= 7)) nw = 12;
             else if (tw == 4 && SRC::PREF_2x8) { tw = 2; nw = 8; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);

@@ -50,7 +50,7 @@ def test_config2_fused_properties_and_sample_parity(kw, prob):
     sl = slice(31337, 31337 + 5000)
     p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d,
                                     lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
-    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_array_equal(le2, le[sl])
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **EVID)   # another launch geometry: the fp32 part of the evidence sums in another order
     np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)               # LDS float atomics: order may differ
     # oracle on a random sample of objects against the FULL model set
     pick = np.random.RandomState(1).choice(n, 100, replace=False)
@@ -123,7 +123,7 @@ def test_config3_full_size_one_million_objects():
     sl = slice(777777, 777777 + 3000)
     p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d, return_gof=True,
                                     save_fits=False, verbose=False)
-    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_array_equal(le2, le[sl])
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **EVID)   # another launch geometry: the fp32 part of the evidence sums in another order
     np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)
     pick = np.random.RandomState(2).choice(n, 40, replace=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
