@@ -11,9 +11,12 @@ One "step" = one pass of the hot path over one batch: N_obj objects x N_model
 models x 5 bands -> N_obj PDFs on the 701-point redshift grid.  Default workload is
 BASELINE.json's headline configuration (1e6 x 1e5 x 5, config index 2).  Inputs are
 synthetic (SURVEY.md section 8d generator) and already resident in HBM when the timed
-region starts; outputs stay in HBM.  Multi-GPU: the object axis is sharded, every
-rank runs the same per-GPU batch (weak scaling), no collective inside the step;
-the optional --gather adds the RCCL all-gather of the PDF shards.
+region starts; outputs stay in HBM.  Multi-GPU (north_star): the N_obj axis of the SAME
+workload is sharded over the ranks in contiguous blocks (strong scaling: 1e6 objects in
+total), models / labels / dictionary are replicated, and every step ends with the RCCL
+all-gather of the (N/P, 701) PDF shards over xGMI, inside the timed region; compute and
+gather times are reported separately.  --scaling weak gives every rank the full batch
+instead, --no-gather leaves the collective out.
 
 Rank 0 prints ONE JSON line.
 """
@@ -31,9 +34,18 @@ sys.path.insert(0, ROOT)
 SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])   # SDSS ugriz 1-sigma depths
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (public spec; = FP64 matrix peak)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-# algorithmic flops per object-model evaluation (add/mul/div/log/exp = 1, fma = 2)
-FLOPS_FUSED = {"A": 58, "B": 64, "Ai": 58, "An": 58, "Bn": 64}
-FLOPS_PASS = {"A": 54, "B": 60, "Ai": 54, "An": 54, "Bn": 60}  # one pass (likelihood 50/56 + max,sub,exp,add)
+
+
+def flops_per_eval(mode, B, fused=True):
+    """algorithmic flops per object-model evaluation (add/mul/div/log/exp = 1, fma = 2): mode A
+    8 per band + 10 for the chi2-distribution epilogue; mode B 4 per band (inter, shape) + 1 + 5 per band
+    (residual form) + 10; + 8 for the fused softmax / threshold / KDE scatter (+ 4 for one statistics pass).
+    B = 5: 58 / 64 fused, as SURVEY 8d states."""
+    if mode not in ("A", "B", "Ai", "An", "Bn"):
+        return None
+    core = (9 * B + 11) if mode in ("B", "Bn") else (8 * B + 10)
+    return core + (8 if fused else 4)
+
 
 MODES = {"A": {}, "B": {"free_scale": True, "ignore_model_err": True},
          "Ai": {"ignore_model_err": True},
@@ -61,6 +73,16 @@ def make_problem(n_obj, n_model, seed, B=5, noise=1.0):
     return Y, Ye, Ym, X, Xe, Xm, z, ze
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
     """The oracle (NumPy port of the reference loop) on a bounded sample of the SAME
     workload: as many objects as fit in ~budget_s seconds against the FULL model set,
@@ -79,7 +101,7 @@ def cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": n * len(Y) / dt, "unit": "evals/s", "pdfs_per_s": n / dt, "cores": 1,
-            "kind": "port",
+            "kind": "port", "cpu": cpu_model(),
             "sample": "%d objects x %d models (full model set), %.1f s, oracle/frankenz_oracle.py "
                       "logprob+logsumexp+gauss_kde_dict loop" % (n, len(Y), dt)}
 
@@ -105,7 +127,7 @@ def cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
     wall = time.perf_counter() - t0
     nobj = sum(r[1] for r in res)
     rate = sum(r[0] for r in res)                    # objects/s, workers timed individually (excludes spawn cost)
-    return {"value": rate * len(Y), "unit": "evals/s", "pdfs_per_s": rate, "cores": ncpu, "kind": "port",
+    return {"value": rate * len(Y), "unit": "evals/s", "pdfs_per_s": rate, "cores": ncpu, "kind": "port", "cpu": cpu_model(),
             "sample": "%d objects x %d models over %d processes, ~%.0f s each (wall %.1f s incl. start-up)"
                       % (nobj, len(Y), ncpu, budget_s, wall)}
 
@@ -118,7 +140,10 @@ def main():
     ap.add_argument("--nobj", type=int, default=1000000, help="objects per GPU per step")
     ap.add_argument("--nmodel", type=int, default=100000)
     ap.add_argument("--mode", choices=sorted(MODES), default="A")
-    ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of PDF shards")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --nobj objects IN TOTAL, sharded over the ranks.  weak: --nobj objects per rank")
+    ap.add_argument("--no-gather", action="store_true", help="leave the RCCL all-gather of the PDF shards out of the step")
+    ap.add_argument("--gather", action="store_true", help="(default for N > 1; kept for compatibility)")
     ap.add_argument("--workload", choices=["fit_predict", "fit", "predict", "knn", "summarize"], default="fit_predict",
                     help="fit_predict: headline fused path (default). fit: materialising BruteForce.fit "
                          "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). predict: "
@@ -144,7 +169,7 @@ def main():
                     help="const: every label carries sigma_z = 0.05 (one dictionary kernel: the histogram + one "
                          "convolution path; every demo of the reference).  varying: sigma_z = U(0.01, 0.1) per model "
                          "(many dictionary kernels: each selected model's window is added)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -152,8 +177,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     kw = MODES[args.mode]
-    N, M = args.nobj, args.nmodel
-    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband, args.noise_scale)
+    M = args.nmodel
+    strong = args.scaling == "strong" and world > 1
+    sys.path.insert(0, ROOT)
+    from frankenz_amd.sharded import shard_slice
+    if strong:
+        # the SAME problem on every rank count: one seed, objects [lo, hi) of the full set on this rank
+        N_total = args.nobj
+        sl = shard_slice(N_total, world, rank); lo, hi = sl.start, sl.stop
+        Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N_total, M, 20260101, args.nband, args.noise_scale)
+        X, Xe, Xm = X[lo:hi], Xe[lo:hi], Xm[lo:hi]
+        N = hi - lo
+        n_pad = -(-N_total // world)                   # rows per rank in the gathered (world * n_pad, G) buffer
+    else:
+        N = args.nobj
+        N_total = N * world
+        n_pad = N
+        Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101 + rank, args.nband, args.noise_scale)
     if args.model_err == "varying":
         Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
     if args.label_err == "varying":
@@ -198,12 +238,13 @@ def main():
         eng.set_labels(z, ze, label_dict=pd)
     dev = torch.device("cuda", local)
     dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
-    d_pdf = torch.empty((N, G), dtype=torch.float64, device=dev)
+    d_pdf = torch.zeros((n_pad, G), dtype=torch.float64, device=dev)         # n_pad >= N rows: equal shards for the all-gather
     d_lm = torch.empty(N, dtype=torch.float64, device=dev)
     d_le = torch.empty(N, dtype=torch.float64, device=dev)
     gathered = None
-    if args.gather and world > 1 and backend == "nccl":
-        gathered = torch.empty((world * N, G), dtype=torch.float64, device=dev)
+    do_gather = world > 1 and not args.no_gather and args.workload == "fit_predict"
+    if do_gather:
+        gathered = torch.empty((world * n_pad, G), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     opts, ko = like_opts(kw), kde_opts({"wt_thresh": args.wt_thresh})
     prior = None
     if args.prior > 0:
@@ -251,10 +292,21 @@ def main():
             eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
             eng.knn_fit_predict(dX, dXe, dXm, d_idx, Kt * kk, opts, ko, pdfs=d_pdf, lmap=d_lm, levid=d_le, n=N)
             return
-        eng.fit_predict_prior(dX, dXe, dXm, opts, ko, prior, d_pdf, d_lm, d_le, n=N)
+        t0 = time.perf_counter()
+        eng.fit_predict_prior(dX, dXe, dXm, opts, ko, prior, d_pdf, d_lm, d_le, n=N)       # returns when the PDFs are in HBM
+        t1 = time.perf_counter()
         if gathered is not None:
-            eng.sync()
-            dist.all_gather_into_tensor(gathered, d_pdf)
+            # RCCL all-gather of the stacked PDFs (north_star).  The step ends only when the collective has
+            # finished: the next step's kernel writes the same shard buffer.
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, d_pdf)
+                torch.cuda.synchronize()
+            else:                                            # plumbing run on a GPU-less / 1-GPU box: gloo over host memory
+                dist.all_gather_into_tensor(gathered, d_pdf.cpu())
+        t2 = time.perf_counter()
+        split[0] += t1 - t0; split[1] += t2 - t1
+
+    split = [0.0, 0.0]              # seconds in compute / in the all-gather over the timed steps
 
     def fence():
         eng.sync()
@@ -263,10 +315,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()        # every torch-side input (prior tables, uniforms) is complete before the library reads it
     for _ in range(args.warmup):
         step()
     fence()
     eng.timing_reset()
+    split[0] = split[1] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -274,9 +328,9 @@ def main():
     dt = time.perf_counter() - t0
     tm = eng.timing()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, split[0], split[1]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, split[0], split[1] = (float(v) for v in t.tolist())
 
     # sanity: PDFs are normalised
     ok = True
@@ -288,7 +342,7 @@ def main():
         if args.workload == "summarize":
             flops = 2.0 * N * G * G * args.steps
             print(json.dumps({"metric": "pdfs_summarize objects/sec (risk GEMM N x G x G fp64 MFMA + per-object statistics)",
-                              "value": world * N * args.steps / dt, "unit": "objects/s", "n_gpus": world, "steps": args.steps,
+                              "value": N_total * args.steps / dt, "unit": "objects/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "pdf.pdfs_summarize: %d PDFs x %d grid points, lorentz kernel" % (N, G)},
                               "roofline": {"bound": "mfma", "kernel": "k_gemm_f64", "achieved": flops / dt / 1e12,
@@ -299,7 +353,7 @@ def main():
             per_launch = N * M / (max(tm["n_planes"], 1) / args.steps)
             gbs = per_launch * 16 / (ms * 1e-3) / 1e9
             print(json.dumps({"metric": "object-template likelihood evals/sec (materialising fit, lnlike+chi2 planes)",
-                              "value": world * N * M * args.steps / dt, "unit": "evals/s", "n_gpus": world,
+                              "value": N_total * M * args.steps / dt, "unit": "evals/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "BruteForce.fit: %d x %d x 5, mode %s, 2 fp64 planes" % (N, M, args.mode)},
@@ -310,8 +364,8 @@ def main():
             ms = (tm["ms_stats"] + tm["ms_kde"] + tm["ms_fused"]) / args.steps
             gbs = N * M * 8 / (ms * 1e-3) / 1e9
             print(json.dumps({"metric": "BruteForce.predict PDFs/sec from a stored (N,M) ln-prob plane",
-                              "value": world * N * args.steps / dt, "unit": "PDFs/s",
-                              "evals_per_s": world * N * M * args.steps / dt, "n_gpus": world,
+                              "value": N_total * args.steps / dt, "unit": "PDFs/s",
+                              "evals_per_s": N_total * M * args.steps / dt, "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "pdfs_normalised": ok, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "BruteForce.predict(logwt=fit_lnprob): %d x %d plane -> %d PDFs" % (N, M, N)},
@@ -321,22 +375,22 @@ def main():
                                            "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))
         else:
             print(json.dumps({"metric": "KMCkNN objects/sec (K=25 exact top-20 searches + subset PDFs)",
-                              "value": world * N * args.steps / dt, "unit": "objects/s",
-                              "search_evals_per_s": world * 25.0 * N * M * args.steps / dt, "n_gpus": world,
+                              "value": N_total * args.steps / dt, "unit": "objects/s",
+                              "search_evals_per_s": 25.0 * N_total * M * args.steps / dt, "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "kernel_ms_per_step": tm["ms_knn"] / args.steps, "pdfs_normalised": ok,
                               "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "NearestNeighbors.fit_predict: %d objects x %d models, K=25 k=20" % (N, M)}}))
 
     if rank == 0 and args.workload == "fit_predict":
-        evals = float(world) * N * M * args.steps
+        evals = float(N_total) * M * args.steps
         value = evals / dt
         # dominant kernel, HIP events on the library's own stream (per launch)
         fam = max(("fused", "stats", "kde", "modec"), key=lambda k: tm["ms_" + k])
         ms_launch = tm["ms_" + fam] / max(tm["n_" + fam], 1)
         launches_per_step = max(tm["n_" + fam], 1) / args.steps
         evals_per_launch = N * M / launches_per_step
-        flops_eval = (FLOPS_FUSED if fam == "fused" else FLOPS_PASS).get(args.mode) if fam != "modec" else None
+        flops_eval = flops_per_eval(args.mode, args.nband, fam == "fused") if fam != "modec" else None
         ach = evals_per_launch * flops_eval / (ms_launch * 1e-3) / 1e12 if flops_eval else None
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -350,19 +404,29 @@ def main():
             "metric": "object-template likelihood evals/sec (fused fit_predict -> PDFs)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
+            "dtype": "f64 (chi2, ln-likes, weights and PDFs of every model within wt_thresh of the best; the sum of the "
+                     "remaining sub-threshold weights in the ln-evidence runs in fp32: DESIGN.md 3.1)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x %d bands per GPU, "
+            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x %d bands%s, "
                                    "BruteForce.fit_predict(save_fits=False), likelihood mode %s, "
-                                   "dict KDE on 701-pt grid" % (N, M, args.nband, args.mode),
-                       "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
+                                   "dict KDE on 701-pt grid" % (N_total, M, args.nband,
+                                                               (" sharded over %d GPUs (object axis, contiguous blocks)" % world)
+                                                               if world > 1 else "", args.mode),
+                       "n_obj_total": N_total, "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
                        "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
                        "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err,
                        "noise_scale": args.noise_scale, "kde": args.kde, "label_err": args.label_err},
             "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "
                      "and mode A runs on the mode-Ai kernels; --model-err varying times the general mode A kernels"
                      if (args.model_err == "const" and args.mode in ("A", "An")) else None),
-            "pdfs_per_s": float(world) * N * args.steps / dt,
+            "pdfs_per_s": float(N_total) * args.steps / dt,
+            "ms_compute": split[0] / args.steps * 1e3, "ms_gather": split[1] / args.steps * 1e3,
+            "gather": ({"collective": "all_gather_into_tensor (RCCL)" if backend == "nccl" else "all_gather (gloo, host)",
+                        "bytes_per_rank": n_pad * G * 8, "bytes_total": world * n_pad * G * 8,
+                        "algbw_GBs": (world * n_pad * G * 8 / (split[1] / args.steps) / 1e9) if split[1] > 0 else None,
+                        "busbw_GBs": (world * n_pad * G * 8 * (world - 1) / world / (split[1] / args.steps) / 1e9) if split[1] > 0 else None}
+                       if gathered is not None else None),
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in
                                    ("fused", "stats", "kde", "planes", "modec", "other")},
@@ -371,13 +435,40 @@ def main():
                          "kernel": "k_" + fam, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of this build), "
+                                           "scaled to this launch; not collected in this run",
                          "flops_per_eval": flops_eval,
                          "avg_launch_ms": ms_launch,
-                         "fused_frac": (N * M * args.steps * FLOPS_FUSED[args.mode]
+                         "fused_frac": (N * M * args.steps * flops_per_eval(args.mode, args.nband)
                                         / ((tm["ms_fused"] + tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
-                                        / FP64_VALU_PEAK_TFLOPS) if args.mode in FLOPS_FUSED else None,
+                                        / FP64_VALU_PEAK_TFLOPS) if flops_per_eval(args.mode, args.nband) else None,
                          "modec_iterations_per_step": (tm["n_modec"] / args.steps - 2) if fam == "modec" else None},   # minus the two timed scopes (iteration driver, final pass)
         }
+        if world == 1 and args.mode == "A" and args.model_err == "const" and not args.prior and args.mask_frac == 0 \
+                and args.kde == "dict" and args.label_err == "const" and args.noise_scale == 1.0 and not os.environ.get("FZ_BENCH_NO_EXTRA"):
+            # the headline configuration has band-constant model errors (the easy case of mode A): the same
+            # workload on the GENERAL mode A kernels (per-model errors) and with the free scale (mode B), two
+            # steps each, so that the driver's record does not only hold the hoisted case
+            def extra(Ye2, kw2, mode2):
+                eng.upload_models(Y, Ye2, Ym)
+                eng.set_labels(z, ze, label_dict=pd)               # labels belong to the model set they were uploaded with
+                o2 = like_opts(kw2)
+                eng.fit_predict_prior(dX, dXe, dXm, o2, ko, None, d_pdf, d_lm, d_le, n=N)
+                eng.timing_reset()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    eng.fit_predict_prior(dX, dXe, dXm, o2, ko, None, d_pdf, d_lm, d_le, n=N)
+                eng.sync()
+                dt2 = (time.perf_counter() - t0) / 2
+                tm2 = eng.timing()
+                ms2 = tm2["ms_fused"] / max(tm2["n_fused"], 1)
+                fl = flops_per_eval(mode2, args.nband)
+                a2 = N * M / (max(tm2["n_fused"], 1) / 2) * fl / (ms2 * 1e-3) / 1e12
+                return {"value": N * M / dt2, "unit": "evals/s", "ms_per_step": dt2 * 1e3, "achieved": a2, "peak": FP64_VALU_PEAK_TFLOPS,
+                        "frac": a2 / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": fl, "avg_launch_ms": ms2}
+            out["roofline_general"] = dict(extra(Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape), {}, "A"),
+                                           note="mode A with per-model errors (--model-err varying): the general kernels")
+            out["roofline_modeB"] = dict(extra(Ye, MODES["B"], "B"), note="free scale, model errors ignored (--mode B)")
         if cpu1 is not None:
             out["cpu_baseline"] = cpu1
             out["speedup_vs_cpu_core"] = value / cpu1["value"]

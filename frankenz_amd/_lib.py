@@ -69,6 +69,7 @@ ABI = {
     "fz_pdfs_summarize": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _P, _P, _F64, _P]),
     "fz_pdfs_resample": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _F64, _F64, _I32, _P]),
     "fz_overlap_nz": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _F64, _P, _P]),
+    "fz_nz_assign": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
     "fz_knn_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
                                            C.POINTER(KdeOpts), C.POINTER(Prior)] + [_P] * 12),
 }

@@ -9,8 +9,14 @@ fit_scale_err, NMODEL, NDIM, NDATA``), return shapes and dtypes.
 
 ``lprob_func`` may be ``None`` or this package's ``logprob`` (the reference default,
 bruteforce.py:105-106), or a ``pdf.logprob_prior`` instance (default likelihood plus
-an additive ln-prior table evaluated on the device).  Any other callable would need a
-per-object host loop; that is refused loudly rather than silently run on the CPU.
+an additive ln-prior table evaluated on the device): those run on the GPU end to end.
+Any other callable -- the reference's plugin hook, bruteforce.py:193-194, e.g. demos/2's
+``lprob_bpz`` -- is the USER's code: it is called once per object on the host exactly as
+the reference calls it (same arguments, ``lprob_args`` / ``lprob_kwargs`` included), its
+``(lnprior, lnlike, lnprob, Ndim, chi2[, scale, scale_err])`` rows fill the ``fit_*``
+arrays, and the softmax / KDE half (bruteforce.py:359-370, 619-629) still runs on the GPU
+from the ln-posterior rows, a chunk at a time.  The likelihood then runs at the speed of
+that callable.
 """
 import sys
 
@@ -24,20 +30,44 @@ __all__ = ["BruteForce"]
 _GEN_CHUNK = 1024     # objects per device call inside the generator twins
 
 
-def _check_lprob(lprob_func, lprob_args, Nmodel=None):
-    """-> the ``logprob_prior`` to apply, or None for the plain likelihood."""
-    if lprob_args:
-        raise NotImplementedError("positional `lprob_args` are not supported; use `lprob_kwargs`")
+_HOST_CHUNK = 256    # objects whose ln-posterior rows are handed to the GPU together (host-callable path)
+
+
+class _HostFunc(object):
+    """a user ``lprob_func`` with its ``lprob_args`` / ``lprob_kwargs``: called per object like
+    bruteforce.py:193-194"""
+
+    def __init__(self, func, args, kwargs):
+        self.func, self.args, self.kwargs = func, list(args or []), dict(kwargs or {})
+
+    def __call__(self, x, xe, xm, bf):
+        return self.func(x, xe, xm, bf.models, bf.models_err, bf.models_mask, *self.args, **self.kwargs)
+
+
+def _check_lprob(lprob_func, lprob_args, Nmodel=None, lprob_kwargs=None):
+    """-> ``(prior, host)``: the ``logprob_prior`` to apply on the device (or None), and the
+    per-object host callable (or None when the device computes the likelihood)."""
     if isinstance(lprob_func, _pdf.logprob_prior):
+        if lprob_args:
+            raise NotImplementedError("positional `lprob_args` are not supported with logprob_prior; use `lprob_kwargs`")
         if Nmodel is not None and lprob_func.M != Nmodel:
             raise ValueError("ln-prior rows hold %d models, the model set %d" % (lprob_func.M, Nmodel))
-        return lprob_func
-    if lprob_func is not None and lprob_func is not _pdf.logprob:
-        raise NotImplementedError(
-            "custom `lprob_func` callables are not supported by the HIP path; use the default "
-            "logprob with `lprob_kwargs` (free_scale, ignore_model_err, dim_prior, ltol), or "
-            "pdf.logprob_prior(lnprior_table, rows) for an additive ln-prior")
-    return None
+        return lprob_func, None
+    if lprob_func is None or lprob_func is _pdf.logprob:
+        if not lprob_args:
+            return None, None
+        lprob_func = _pdf.logprob          # positional arguments: the reference's call, per object
+    if not callable(lprob_func):
+        raise ValueError("`lprob_func` must be callable")
+    return None, _HostFunc(lprob_func, lprob_args, lprob_kwargs)
+
+
+def _check_logwt(lw, Ndata, Nlabels):
+    """the C side reads ``Ndata`` rows of ``len(model_labels)`` weights: refuse anything else here
+    (the reference would raise an IndexError / broadcast error from NumPy)"""
+    if lw.ndim != 2 or lw.shape[1] != Nlabels or lw.shape[0] < Ndata:
+        raise ValueError("`logwt` has shape %s; expected at least (%d, %d) = (Ndata, len(model_labels))"
+                         % (lw.shape, Ndata, Nlabels))
 
 
 def _progress(verbose, what, i, n):
@@ -97,6 +127,56 @@ class BruteForce():
                       self.fit_lnlike[sl], self.fit_lnprob[sl], self.fit_chi2[sl], self.fit_Ndim[sl],
                       sc, se, n=hi - lo)
 
+    def _store_row(self, i, results, track_scale):
+        """bruteforce.py:195-203"""
+        self.fit_lnprior[i] = results[0]
+        self.fit_lnlike[i] = results[1]
+        self.fit_lnprob[i] = results[2]
+        self.fit_Ndim[i] = results[3]
+        self.fit_chi2[i] = results[4]
+        if track_scale:
+            self.fit_scale[i] = results[5]
+            self.fit_scale_err[i] = results[6]
+
+    def _host_fit(self, host, data, data_err, data_mask, track_scale, save_fits):
+        """bruteforce.py:191-205 with a user callable: a host loop, as in the reference."""
+        Ndata = len(data)
+        self.NDATA = Ndata
+        if save_fits:
+            self._alloc_fits(Ndata)
+        for i, (x, xe, xm) in enumerate(zip(data, data_err, data_mask)):
+            results = host(x, xe, xm, self)
+            if save_fits:
+                self._store_row(i, results, track_scale)
+            yield results
+
+    def _host_fit_predict(self, host, data, data_err, data_mask, model_labels, model_label_errs, label_dict,
+                          label_grid, kde_kwargs, track_scale, save_fits):
+        """bruteforce.py:602-631 with a user callable: its ln-posterior rows (bruteforce.py:616) go to
+        the GPU ``_HOST_CHUNK`` objects at a time for max / logsumexp / KDE / normalisation."""
+        ko = kde_opts(kde_kwargs)
+        eng = get_engine(self._device)
+        Ndata = len(data)
+        if save_fits:
+            self.NDATA = Ndata
+            self._alloc_fits(Ndata)
+        for lo in range(0, Ndata, _HOST_CHUNK):
+            hi = min(Ndata, lo + _HOST_CHUNK)
+            plane = np.empty((hi - lo, self.NMODEL))
+            for i in range(lo, hi):
+                results = host(data[i], data_err[i], data_mask[i], self)
+                if save_fits:
+                    self._store_row(i, results, track_scale)
+                plane[i - lo] = results[2]
+            # (after the callbacks: a callable that itself uses this package's likelihood re-uploads model
+            # sets, and labels belong to the model set they were uploaded with)
+            Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
+            pdfs = np.zeros((hi - lo, Nx))
+            lmap, levid = np.zeros(hi - lo), np.zeros(hi - lo)
+            eng.predict_logwt(plane, ko, pdfs, lmap, levid, n=hi - lo)
+            for i in range(hi - lo):
+                yield pdfs[i], (lmap[i], levid[i])
+
     def _row_results(self, i, track_scale):
         r = (self.fit_lnprior[i], self.fit_lnlike[i], self.fit_lnprob[i], self.fit_Ndim[i],
              self.fit_chi2[i])
@@ -108,7 +188,14 @@ class BruteForce():
     def fit(self, data, data_err, data_mask, lprob_func=None, lprob_args=None, lprob_kwargs=None,
             track_scale=False, verbose=True):
         """bruteforce.py:66-125.  Fills the (Ndata, Nmodel) ``fit_*`` arrays."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
+        if host is not None:
+            for i, _ in enumerate(self._host_fit(host, data, data_err, data_mask, track_scale, True)):
+                _progress(verbose, 'Fitting object', i + 1, len(data))
+            if verbose:
+                sys.stderr.write('\n')
+                sys.stderr.flush()
+            return
         opts = like_opts(lprob_kwargs)
         eng = self._engine()
         obj = HostObjects(data, data_err, data_mask)
@@ -128,7 +215,11 @@ class BruteForce():
     def _fit(self, data, data_err, data_mask, lprob_func=None, lprob_args=None, lprob_kwargs=None,
              track_scale=False, save_fits=True):
         """Generator twin (bruteforce.py:127-205): yields the per-object result tuple."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
+        if host is not None:
+            for results in self._host_fit(host, data, data_err, data_mask, track_scale, save_fits):
+                yield results
+            return
         opts = like_opts(lprob_kwargs)
         eng = self._engine()
         obj = HostObjects(data, data_err, data_mask)
@@ -168,6 +259,7 @@ class BruteForce():
         ko = kde_opts(kde_kwargs)
         lw = np.ascontiguousarray(logwt, dtype=np.float64)
         Ndata = self.NDATA if self.NDATA is not None else len(lw)
+        _check_logwt(lw, Ndata, len(model_labels))
         pdfs = np.zeros((Ndata, Nx))
         lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
         eng.predict_logwt(lw, ko, pdfs, lmap, levid, n=Ndata)
@@ -195,6 +287,7 @@ class BruteForce():
         for lo in range(0, n, _GEN_CHUNK):
             hi = min(n, lo + _GEN_CHUNK)
             lw = np.ascontiguousarray(logwt[lo:hi], dtype=np.float64)
+            _check_logwt(lw, hi - lo, len(model_labels))
             pdfs = np.zeros((hi - lo, Nx))
             lmap, levid = np.zeros(hi - lo), np.zeros(hi - lo)
             eng.predict_logwt(lw, ko, pdfs, lmap, levid)
@@ -208,11 +301,25 @@ class BruteForce():
                     track_scale=False, verbose=True, save_fits=True):
         """bruteforce.py:374-503.  ``save_fits=False`` is the streaming path that never
         materialises (Ndata, Nmodel); ``save_fits=True`` additionally fills ``fit_*``."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
         if kde_args:
             raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
+        if host is not None:
+            Ndata = len(data)
+            rows = []
+            for i, r in enumerate(self._host_fit_predict(host, data, data_err, data_mask, model_labels, model_label_errs,
+                                                          label_dict, label_grid, kde_kwargs, track_scale, save_fits)):
+                rows.append(r)
+                _progress(verbose, 'Generating PDF', i + 1, Ndata)
+            if verbose:
+                sys.stderr.write('\n')
+                sys.stderr.flush()
+            pdfs = np.array([r[0] for r in rows]) if rows else np.zeros((0, 0))
+            if return_gof:
+                return pdfs, (np.array([r[1][0] for r in rows]), np.array([r[1][1] for r in rows]))
+            return pdfs
         opts = like_opts(lprob_kwargs)
         ko = kde_opts(kde_kwargs)
         eng = self._engine()
@@ -245,11 +352,16 @@ class BruteForce():
                      kde_kwargs=None, lprob_args=None, lprob_kwargs=None, track_scale=False,
                      save_fits=True):
         """Generator twin (bruteforce.py:505-631): yields ``(pdf, (lmap, levid))``."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
         if kde_args:
             raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
+        if host is not None:
+            for r in self._host_fit_predict(host, data, data_err, data_mask, model_labels, model_label_errs, label_dict,
+                                            label_grid, kde_kwargs, track_scale, save_fits):
+                yield r
+            return
         opts = like_opts(lprob_kwargs)
         ko = kde_opts(kde_kwargs)
         eng = self._engine()

@@ -255,7 +255,8 @@ __global__ void k_prep_grid_labels(const double* y, const double* ystd, int64_t 
     if (!(cd == cd) || !(od == od) || fabs(cd) > 1e15 || fabs(od) > 1e15) { atomicOr(flags, 1); up = 0; dn = 0; }
     if (up > G) up = G;
     if (dn < 0) dn = 0;
-    if (up < 0 || dn > G) { atomicOr(flags, 2); }      // Python slice would wrap / be empty oddly
+    if (up < 0) { atomicOr(flags, 2); }                // x[dn:up] with a negative upper bound wraps around in Python: not reproduced
+    if (dn > G) dn = G;                                // window wholly above the grid: an empty slice, sum 0, kernel skipped (pdf.py:519-523)
     if (up < dn) up = dn;
     lo[j] = (int32_t)dn; hi[j] = (int32_t)up;
     const double mu = y[j], sd = ystd[j], gn = 2.5066282746310002 * sd;
@@ -295,7 +296,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     int fl = 0;
     FZCHK(copy_out(c, &fl, c->d_flags.p, sizeof fl));
     if (fl & 1) return fail(-4, "gauss_kde labels: non-finite label or label error");
-    if (fl & 2) return fail(-3, "gauss_kde labels: a label's window lies wholly off the grid "
+    if (fl & 2) return fail(-3, "gauss_kde labels: a label's window lies wholly below the grid "
                                 "(the reference's negative-index slicing there is not reproduced)");
     c->G = G; c->label_mode = 2; c->label_M = M;
     return 0;
@@ -332,6 +333,17 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
     }
     if (derive) { bits[i] = bt; slv[i] = sl; }
     if (fl) atomicOr(flags, fl);
+}
+
+// Stream-ordering contract of the ABI (include/frankenz_hip.h): the library works on its own
+// non-blocking stream.  Arguments in device memory may have been produced by kernels the caller
+// queued on ANY stream, so every entry point that accepts device pointers first waits for the
+// device (hipDeviceSynchronize: ~10 us when idle), and returns only when its own work is done.
+static int wait_for_producers(fz_ctx* c, std::initializer_list<const void*> ptrs) {
+    (void)c;
+    for (const void* p : ptrs)
+        if (is_device_ptr(p)) { HIPCHK(hipDeviceSynchronize()); break; }
+    return 0;
 }
 
 // stage a chunk of raw objects on the device (no-op views for device pointers),
@@ -582,6 +594,7 @@ extern "C" int fz_fit_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_
     if (!c->M) return fail(-1, "fz_fit: models have not been uploaded");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    FZCHK(wait_for_producers(c, {x, xe, xm, pr ? pr->table : nullptr, pr ? pr->rows : nullptr}));
     const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M;
     PriorBind pb; PriorGuard guard{c};
@@ -643,6 +656,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     FZCHK(check_kde_opts(ko));
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    FZCHK(wait_for_producers(c, {x, xe, xm, pr ? pr->table : nullptr, pr ? pr->rows : nullptr}));
     const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M, G = c->G;
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
@@ -777,6 +791,7 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
     if (c->label_mode == 0) return fail(-1, "fz_predict_logwt: labels have not been uploaded");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    FZCHK(wait_for_producers(c, {logwt}));
     const int64_t M = c->label_M, G = c->G;
     const bool in_dev = is_device_ptr(logwt), pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
     const int linear = is_log ? 0 : 1;

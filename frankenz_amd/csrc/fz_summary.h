@@ -7,6 +7,7 @@
 //   k_summarize  everything per object: mean / mode / CDF quantiles / argmin of the risk row /
 //                second moments / windowed CDF mass / interpolated risk (pdf.py:987-1068)
 //   k_overlap    overlap = pdfs @ nz (+ pair step), sum of logs (samplers.py:66-76) HBM-bound
+//   k_nz_assign  one categorical draw per object from pdf_i * nz (samplers.py:498-499, 519-520)  HBM-bound
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -307,6 +308,47 @@ static __global__ __launch_bounds__(256) void k_overlap(const double* __restrict
     if (lane == 0) part[threadIdx.x >> 6] = lg;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// ---- per-object categorical draw of the hierarchical / population samplers ---------------------
+// samplers.py:498-499, 519-520 draw  multinomial(1, p * pos / dot(p, pos))  for every object in
+// every Gibbs sweep (N x G work) and sum the one-hot rows.  Here: the draw by inverse CDF with a
+// uniform supplied by the caller (u[i] in [0, 1)) -- bin = the number of grid points whose running
+// sum of p[g] * nz[g] is <= u * total -- one wave per object, the row read once; counts are summed
+// with integer atomics (order-free).  A row without mass (total <= 0 or not finite) gets bin -1.
+static __global__ __launch_bounds__(256) void k_nz_assign(const double* __restrict__ pdfs, int64_t N, int G,
+                                                          const double* __restrict__ nz, const double* __restrict__ u,
+                                                          int64_t* __restrict__ bins, unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const double* p = pdfs + i * G;
+    // every lane owns a CONTIGUOUS run of grid points, so that the running sum is monotone across lanes
+    const int per = (G + 63) / 64;
+    const int g0 = lane * per, g1 = min(G, g0 + per);
+    double s = 0.0;
+    for (int g = g0; g < g1; ++g) s += p[g] * nz[g];
+    // exclusive prefix over the lanes (Hillis-Steele on the lane sums)
+    double incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const double total = __shfl(incl, 63, 64);
+    int64_t bin = -1;
+    if (total > 0.0 && total - total == 0.0) {
+        const double target = u[i] * total;
+        // the lane whose run holds the crossing: inclusive sum > target, exclusive sum <= target
+        const double excl = incl - s;
+        // (the owner must hold mass itself: the tree-ordered lane prefix is monotone only up to rounding)
+        const unsigned long long mass = __ballot(s > 0.0), at = __ballot(incl > target) & mass;
+        // rounding at the very top (u * total == total): the last lane that holds any mass, its last such point
+        const int owner = at ? __builtin_ctzll(at) : 63 - __builtin_clzll(mass);
+        if (lane == owner) {
+            double c = excl; int g = g0, last = g0;
+            for (; g < g1; ++g) { const double w = p[g] * nz[g]; if (w > 0.0) last = g; c += w; if (at && c > target) break; }
+            bin = (g < g1) ? g : last;                           // (run exhausted: by rounding, or at the top: its last point with mass)
+            bins[i] = bin;
+            atomicAdd(&counts[bin], 1ull);
+        }
+    } else if (lane == 0) bins[i] = -1;
 }
 // fixed-order sum of the block partials (one block): the result does not depend on scheduling
 static __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int64_t n, double* __restrict__ out) {

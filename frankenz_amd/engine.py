@@ -197,6 +197,10 @@ class Engine(object):
         check(self.lib.fz_pdfs_resample(self.h, ptr(pdfs), n, len(old_grid), ptr(old_grid), len(new_grid), ptr(new_grid),
                                         float(left), float(right), int(bool(renormalize)), ptr(out)))
 
+    def nz_assign(self, pdfs, nz, u, bins, counts, n=None):
+        n = len(pdfs) if n is None else n
+        check(self.lib.fz_nz_assign(self.h, ptr(pdfs), n, len(nz), ptr(nz), ptr(u), ptr(bins), ptr(counts)))
+
     def overlap_nz(self, pdfs, nz, pair, step, overlap, n=None):
         n = len(pdfs) if n is None else n
         out = np.zeros(1)

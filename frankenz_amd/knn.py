@@ -182,15 +182,61 @@ class NearestNeighbors():
             self.fit_lnprior[sl] = np.where(valid, 0.0, -np.inf)          # knn.py:852: zeros on the subset
         return idx
 
+    def _host_run(self, host, data, data_err, data_mask, rstate, track_scale, labels=None):
+        """knn.py:355-388 / 826-874 with a user ``lprob_func``: the K searches and the first-appearance
+        de-duplication run on the GPU (on copies: only the user's callable may touch the caller's rows),
+        the callable is evaluated per object on its neighbour subset like the reference does, and -- with
+        ``labels = (model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)`` -- the PDFs come
+        from the GPU out of the stored ln-posterior rows.  Fills the padded ``fit_*`` arrays."""
+        if rstate is None:
+            rstate = np.random
+        eng = self._engine()
+        q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
+        Ndata = len(data)
+        self.NDATA = Ndata
+        self._alloc_fits(Ndata)
+        scratch = HostObjects(np.array(data, dtype=float), np.array(data_err, dtype=float), np.array(data_mask, dtype=float))
+        self._run(eng, scratch, q, 0, Ndata, like_opts(None), None, False, True)     # neighbours; the default fits are overwritten below
+        W = self.K * self.k
+        inf = np.inf
+        self.fit_lnprior[:] = -inf; self.fit_lnlike[:] = -inf; self.fit_lnprob[:] = -inf
+        self.fit_Ndim[:] = 0; self.fit_chi2[:] = inf; self.fit_scale[:] = 1.; self.fit_scale_err[:] = 0.
+        out = []
+        for i, (x, xe, xm) in enumerate(zip(data, data_err, data_mask)):
+            n = self.Nneighbors[i]
+            idxs = self.neighbors[i, :n]
+            results = host.func(x, xe, xm, self.models[idxs], self.models_err[idxs], self.models_mask[idxs],
+                                *host.args, **host.kwargs)
+            self.fit_lnprior[i, :n] = results[0]
+            self.fit_lnlike[i, :n] = results[1]
+            self.fit_lnprob[i, :n] = results[2]
+            self.fit_Ndim[i, :n] = results[3]
+            self.fit_chi2[i, :n] = results[4]
+            if track_scale:
+                self.fit_scale[i, :n] = results[5]
+                self.fit_scale_err[i, :n] = results[6]
+            out.append((idxs, n, results))
+        if labels is None:
+            return out
+        ml, mle, ld, lg, kk = labels
+        return self.predict(ml, mle, label_dict=ld, label_grid=lg, kde_kwargs=kk, return_gof=True, verbose=False)
+
     # ------------------------------------------------------------------
     def fit(self, data, data_err, data_mask, lprob_func=None, rstate=None, k=20, eps=1e-3, lp_norm=2,
             distance_upper_bound=np.inf, lprob_args=None, lprob_kwargs=None, track_scale=False, verbose=True):
         """knn.py:190-279."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
-        opts = like_opts(lprob_kwargs)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
+        opts = like_opts(lprob_kwargs) if host is None else None
         if rstate is None:
             rstate = np.random
         self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        if host is not None:
+            self._host_run(host, data, data_err, data_mask, rstate, track_scale)
+            _progress(verbose, 'Fitting object', len(data), len(data))
+            if verbose:
+                sys.stderr.write('\n')
+                sys.stderr.flush()
+            return
         eng = self._engine()
         q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
         obj = HostObjects(data, data_err, data_mask)
@@ -208,11 +254,16 @@ class NearestNeighbors():
              track_scale=False, save_fits=True):
         """Generator twin (knn.py:281-388): yields ``(idxs, Nidx, results)`` per object;
         uses the ``k / eps / lp_norm / dbound`` attributes like the reference."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
-        opts = like_opts(lprob_kwargs)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
+        opts = like_opts(lprob_kwargs) if host is None else None
         if rstate is None:
             rstate = np.random
         self._search_setup(self.k, self.eps, self.lp_norm, self.dbound)
+        if host is not None:
+            keep = self if save_fits else copy.copy(self)
+            for r in keep._host_run(host, data, data_err, data_mask, rstate, track_scale):
+                yield r
+            return
         eng = self._engine()
         q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
         obj = HostObjects(data, data_err, data_mask)
@@ -252,6 +303,8 @@ class NearestNeighbors():
         lw = np.ascontiguousarray(logwt, dtype=np.float64)
         nb = np.ascontiguousarray(self.neighbors, dtype=np.int64)
         nn = np.ascontiguousarray(self.Nneighbors, dtype=np.int64)
+        if lw.shape != (Ndata, W) or nb.shape != (Ndata, W) or nn.shape != (Ndata,):
+            raise ValueError("`logwt` has shape %s; expected (Ndata, K*k) = (%d, %d) like `neighbors`" % (lw.shape, Ndata, W))
         eng.knn_predict_logwt(lw, nb, nn, W, ko, pdfs, lmap, levid, n=Ndata)
         _progress(verbose, 'Generating PDF', Ndata, Ndata)
         if verbose:
@@ -276,16 +329,25 @@ class NearestNeighbors():
                     label_grid=None, kde_args=None, kde_kwargs=None, lprob_args=None, lprob_kwargs=None,
                     return_gof=False, track_scale=False, verbose=True, save_fits=True):
         """knn.py:560-720."""
-        prior = _check_lprob(lprob_func, lprob_args, self.NMODEL)
+        prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
         if kde_args:
             raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
-        opts = like_opts(lprob_kwargs)
-        ko = kde_opts(kde_kwargs)
         if rstate is None:
             rstate = np.random
         self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        if host is not None:
+            keep = self if save_fits else copy.copy(self)
+            pdfs, gof = keep._host_run(host, data, data_err, data_mask, rstate, track_scale,
+                                       labels=(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs))
+            _progress(verbose, 'Generating PDF', len(data), len(data))
+            if verbose:
+                sys.stderr.write('\n')
+                sys.stderr.flush()
+            return (pdfs, gof) if return_gof else pdfs
+        opts = like_opts(lprob_kwargs)
+        ko = kde_opts(kde_kwargs)
         eng = self._engine()
         Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
         q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)

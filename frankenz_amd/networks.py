@@ -2,9 +2,10 @@
 Mapping models onto the nodes of a trained network (SOM / GNG) -- the inference step
 ``_Network.populate_network`` of the reference (frankenz/networks.py:176-356).
 The (Nmodel, Nnode) likelihoods, the hot part, run on the GPU through the same kernels as
-``BruteForce.fit`` with the nodes as noiseless models (networks.py:305-307); the ragged
-per-node lists are host bookkeeping, as in the reference.  Training the network is out of
-scope.
+``BruteForce.fit`` with the nodes as noiseless models (networks.py:305-307).  The thresholding,
+the per-model max / logsumexp and the ragged per-node lists are segmented NumPy reductions over
+the (model, node) pair list of the whole plane -- no per-model Python loop.  Training the network
+is out of scope.
 """
 import numpy as np
 from scipy.special import logsumexp
@@ -44,41 +45,58 @@ def populate_network(nodes, models, models_err, models_mask, lpnet_kwargs=None, 
     obj.writeback()
     if track_scale and not free:
         raise ValueError("track_scale=True needs a likelihood that returns the scale (free_scale=True)")
+    return _lists_from_plane(lnprob, scale, scale_err, wt_thresh, cdf_thresh, track_scale)
+
+
+def _lists_from_plane(lnprob, scale, scale_err, wt_thresh, cdf_thresh, track_scale):
+    """the (Nmodels, Nnodes) ln-prob plane -> the per-model selections and the per-node lists"""
+    Nmodels, Nnodes = lnprob.shape
     out = NetworkMap()
-    out.nodes_idxs = [[] for _ in range(Nnodes)]
-    out.nodes_logwts = [[] for _ in range(Nnodes)]
-    out.nodes_bmus = [[] for _ in range(Nnodes)]
-    out.nodes_scales = [[] for _ in range(Nnodes)]
-    out.nodes_scales_err = [[] for _ in range(Nnodes)]
-    out.nodes_Nmatch = np.zeros(Nnodes, dtype='int')
-    out.models_lmap = np.zeros(Nmodels) - np.inf
-    out.models_levid = np.zeros(Nmodels) - np.inf
-    out.results = []
-    for i in range(Nmodels):
-        node_lnprob = lnprob[i]
-        out.nodes_bmus[int(np.argmax(node_lnprob))].append(i)
-        if wt_thresh is not None:
-            lwt_min = np.log(wt_thresh) + np.max(node_lnprob)
-            n_idxs = np.arange(Nnodes)[node_lnprob > lwt_min]
-        else:
-            idx_sort = np.argsort(node_lnprob)
-            node_prob = np.exp(node_lnprob - logsumexp(node_lnprob))
-            node_cdf = np.cumsum(node_prob[idx_sort])
-            n_idxs = idx_sort[node_cdf <= (1. - cdf_thresh)]
-        n_lnprobs = node_lnprob[n_idxs]
-        n_lmap, n_levid = np.max(n_lnprobs), logsumexp(n_lnprobs)
-        n_lnprobs -= n_levid
-        out.models_lmap[i] = n_lmap
-        out.models_levid[i] = n_levid
-        if track_scale:
-            n_scales, n_scales_err = scale[i][n_idxs], scale_err[i][n_idxs]
-        else:
-            n_scales, n_scales_err = np.ones_like(n_idxs), np.zeros_like(n_idxs)
-        for j, lwt, s, serr in zip(n_idxs, n_lnprobs, n_scales, n_scales_err):
-            out.nodes_idxs[j].append(i)
-            out.nodes_logwts[j].append(lwt)
-            out.nodes_scales[j].append(s)
-            out.nodes_scales_err[j].append(serr)
-            out.nodes_Nmatch[j] += 1
-        out.results.append((n_idxs, n_lnprobs, n_scales, n_scales_err))
+    # Everything below works on the whole (Nmodels, Nnodes) plane at once; the reference walks the models
+    # one by one (networks.py:310-354).  What it leaves behind is reproduced through the ORDER of the
+    # (model, node) pairs: models ascending, and inside a model the reference's own node order
+    # (ascending node index under wt_thresh, ascending ln-prob under the CDF rule).
+    rows = np.arange(Nmodels)
+    out.models_bmu = np.argmax(lnprob, axis=1)                       # best-matching unit per model
+    if wt_thresh is not None:
+        keep = lnprob > (np.log(wt_thresh) + lnprob.max(axis=1))[:, None]          # strict, networks.py:319-321
+        pair_model, pair_node = np.nonzero(keep)                     # row-major: node index ascending inside a model
+    else:
+        order = np.argsort(lnprob, axis=1)                           # networks.py:323-327: ascending sort, keep cdf <= 1 - cdf_thresh
+        prob = np.exp(lnprob - logsumexp(lnprob, axis=1)[:, None])
+        cdf = np.cumsum(np.take_along_axis(prob, order, axis=1), axis=1)
+        pair_model, col = np.nonzero(cdf <= (1. - cdf_thresh))
+        pair_node = order[pair_model, col]
+    pair_lnp = lnprob[pair_model, pair_node]
+    # per-model max and logsumexp of the kept entries (segmented reductions over the pair list)
+    counts = np.bincount(pair_model, minlength=Nmodels)
+    starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    has = counts > 0
+    lmap = np.full(Nmodels, -np.inf)
+    lmap[has] = np.maximum.reduceat(pair_lnp, starts[has])
+    shifted = np.exp(pair_lnp - lmap[pair_model])
+    ssum = np.zeros(Nmodels)
+    ssum[has] = np.add.reduceat(shifted, starts[has])
+    with np.errstate(divide='ignore'):
+        levid = lmap + np.log(ssum)
+    levid[~has] = -np.inf
+    out.models_lmap, out.models_levid = lmap, levid
+    pair_logwt = pair_lnp - levid[pair_model]                        # networks.py:331
+    if track_scale:
+        pair_s, pair_se = scale[pair_model, pair_node], scale_err[pair_model, pair_node]
+    else:
+        pair_s, pair_se = np.ones_like(pair_node), np.zeros_like(pair_node)        # integer ones / zeros like the reference
+    # per-node lists: the pairs regrouped by node, models ascending within a node (stable sort)
+    by_node = np.argsort(pair_node, kind='stable')
+    cuts = np.cumsum(np.bincount(pair_node, minlength=Nnodes))[:-1]
+    out.nodes_idxs = [a.tolist() for a in np.split(pair_model[by_node], cuts)]
+    out.nodes_logwts = [a.tolist() for a in np.split(pair_logwt[by_node], cuts)]
+    out.nodes_scales = [a.tolist() for a in np.split(pair_s[by_node], cuts)]
+    out.nodes_scales_err = [a.tolist() for a in np.split(pair_se[by_node], cuts)]
+    out.nodes_Nmatch = np.bincount(pair_node, minlength=Nnodes).astype('int')
+    bmu_order = np.argsort(out.models_bmu, kind='stable')
+    out.nodes_bmus = [a.tolist() for a in np.split(rows[bmu_order], np.cumsum(np.bincount(out.models_bmu, minlength=Nnodes))[:-1])]
+    # the per-model tuples the reference's generator yields
+    mcuts = np.cumsum(counts)[:-1]
+    out.results = list(zip(np.split(pair_node, mcuts), np.split(pair_logwt, mcuts), np.split(pair_s, mcuts), np.split(pair_se, mcuts)))
     return out

@@ -63,7 +63,7 @@ def logprob(data, data_err, data_mask, models, models_err, models_mask, free_sca
                   free_scale=free_scale, ignore_model_err=ignore_model_err, dim_prior=dim_prior,
                   ltol=ltol, return_scale=return_scale, *args, **kwargs)
     lnl = res[0]
-    return (np.zeros_like(lnl), lnl, lnl[:]) + tuple(res[1:])
+    return (np.zeros_like(lnl), lnl, lnl.copy()) + tuple(res[1:])       # lnprob = lnlike + lnprior is a fresh array in the reference (pdf.py:405)
 
 
 class logprob_prior(object):
@@ -180,6 +180,8 @@ def gauss_kde(y, y_std, x, dx=None, y_wt=None, sig_thresh=5., wt_thresh=1e-3, cd
     eng = get_engine(device)
     y = np.asarray(y, dtype=float)
     wt = np.ones(len(y)) if y_wt is None else np.ascontiguousarray(y_wt, dtype=np.float64)
+    if wt.shape != (len(y),) or len(np.atleast_1d(y_std)) != len(y):
+        raise ValueError("`y`, `y_std` and `y_wt` must have the same length")
     eng.upload_labels_grid(y, y_std, x, dx=dx, sig_thresh=sig_thresh)
     out = np.empty((1, len(x)))
     ko = kde_opts(dict(wt_thresh=wt_thresh, cdf_thresh=cdf_thresh), normalize=False)
@@ -199,6 +201,8 @@ def gauss_kde_dict(pdfdict, y=None, y_std=None, y_idx=None, y_std_idx=None, y_wt
                          "be specified.")
     eng = get_engine(device)
     wt = np.ones(len(y_idx)) if y_wt is None else np.ascontiguousarray(y_wt, dtype=np.float64)
+    if wt.shape != (len(y_idx),) or len(y_std_idx) != len(y_idx):
+        raise ValueError("`y_idx`, `y_std_idx` and `y_wt` must have the same length")
     eng.upload_dict(pdfdict)
     eng.upload_labels_dict(y_idx, y_std_idx)
     out = np.empty((1, pdfdict.Ngrid))

@@ -16,6 +16,12 @@
  *    the library detects which (hipPointerGetAttributes) and stages host arrays
  *    through its own buffers.  Output pointers may be NULL = "not wanted".
  *  - masks are float64 0/1 (the reference's demos use np.ones_like(phot)).
+ *  - STREAM ORDERING.  The library runs on a stream of its own.  An entry point that is
+ *    handed device pointers first waits for ALL work queued on the device so far
+ *    (hipDeviceSynchronize), so inputs produced by kernels on any caller stream are
+ *    complete before they are read; and every entry point returns only when its own
+ *    work has finished, so outputs may be consumed from any stream at once.  No
+ *    caller-side synchronisation is needed on either side of a call.
  *  - one fz_ctx per device; a ctx is not thread-safe.
  */
 #ifndef FRANKENZ_HIP_H
@@ -201,6 +207,16 @@ int  fz_pdfs_resample(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, con
 int  fz_overlap_nz(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const double* nz,
                    int64_t pair_i, int64_t pair_j, double pair_step, double* overlap,
                    double* lnlike);
+
+/* samplers.py:498-499, 519-520 -- the redshift-assignment step of the hierarchical / population
+ * Gibbs samplers: one categorical draw per object from  pdfs[i] * nz / dot(pdfs[i], nz).  The
+ * reference draws rstate.multinomial(1, ...) per object in a Python list comprehension and sums the
+ * one-hot rows; here the draw is the inverse CDF of the caller's uniform u[i] in [0, 1)
+ * (bin = number of grid points with running sum <= u[i] * total), so the caller keeps the random
+ * stream.  bins (N, int64; -1 for a row without mass; may be NULL) and counts (G, int64: objects per
+ * bin, i.e. the summed one-hot rows). */
+int  fz_nz_assign(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const double* nz, const double* u,
+                  int64_t* bins, int64_t* counts);
 
 /* diagnostic: evaluate one of the library's device math helpers elementwise
  * (which: 0 v_rcp_f64 seed, 1 / 2 rcp with one / two Newton steps, 3 log_pos,

@@ -513,6 +513,49 @@ def g11():
     save('g11_network_map', **out)
 
 
+def g12():
+    """configs[4] substitute (SURVEY 8d "Config 5"; the SDSS_DR13 FITS file is not in the reference tree):
+    an SDSS-like catalogue from the reference's own simulator (the g7 recipe scaled to 2000 objects),
+    fitted by the reference's BruteForce (i) against a 125 z x 8 template model grid with the free scale and
+    (ii) against a 1500-object training set with the default likelihood; stored: every 10th per-object
+    PDF, lmap / levid of all, the stack  sum_i pdf_i  (the population n(z) estimate the 8-GPU run
+    all-reduces) and samplers.loglike_nz of that stack and of a flat n(z) with its per-object overlaps."""
+    from frankenz import simulate, samplers
+    np.random.seed(12)
+    ms = simulate.MockSurvey()
+    ms.load_survey('sdss', Npoints=50000)
+    ms.set_refmag('r')
+    ms.load_templates('cww+')
+    ms.load_prior('bpz')
+    ms.make_mock(3500, mbounds=[16, 25], zbounds=[0, 6], verbose=False)
+    zgrid = np.linspace(0, 6, 125)
+    ms.make_model_grid(zgrid, verbose=False)
+    obs_all = np.array(ms.data['phot_obs']); err_all = np.array(ms.data['phot_err']); zs_all = np.array(ms.data['redshifts'])
+    obs, err, zs = obs_all[:2000], err_all[:2000], zs_all[:2000]
+    tr_obs, tr_err, tr_z = obs_all[2000:], err_all[2000:], zs_all[2000:]
+    mg = np.array(ms.models['data'])
+    nz_, nt, nf = mg.shape
+    mphot = mg.reshape(nz_ * nt, nf)
+    mz = np.repeat(zgrid, nt)
+    d = demo_dict()
+    out = dict(obs=obs, err=err, redshifts=zs, mphot=mphot, mz=mz, tr_obs=tr_obs, tr_err=tr_err, tr_z=tr_z)
+    kw = {'free_scale': True, 'ignore_model_err': True}
+    for tag, bf, lab, lerr, lk in (('grid', BruteForce(mphot, np.zeros_like(mphot), np.ones_like(mphot)), mz, np.full(len(mz), 0.03), kw),
+                                   ('train', BruteForce(tr_obs, tr_err, np.ones_like(tr_obs)), tr_z, np.full(len(tr_z), 0.05), {})):
+        p, (lm, le) = bf.fit_predict(obs.copy(), err.copy(), np.ones_like(obs), lab, lerr, label_dict=d, lprob_kwargs=lk,
+                                     return_gof=True, verbose=False, save_fits=False)
+        assert np.isfinite(p).all()
+        stack = p.sum(axis=0)
+        out[tag + '_pdfs_every10'] = p[::10]
+        out[tag + '_lmap'], out[tag + '_levid'] = lm, le
+        out[tag + '_stack'] = stack
+        for nm, nzv in (('stack', stack / stack.sum()), ('flat', np.full(len(stack), 1. / len(stack)))):
+            ll, ov = samplers.loglike_nz(nzv, p, return_overlap=True)
+            out['%s_llnz_%s' % (tag, nm)] = ll
+            out['%s_overlap_%s' % (tag, nm)] = ov
+    save('g12_catalogue_stack', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for nm in sys.argv[1:]:
@@ -521,4 +564,6 @@ if __name__ == '__main__':
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
-    g1(); g2(); g3(); g4(); g5(); g6(); g7(); g8(); g9(); g10(); g11()
+    which = sys.argv[1:] or ['g%d' % k for k in range(1, 13)]
+    for name in which:
+        globals()[name]()

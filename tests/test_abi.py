@@ -63,8 +63,17 @@ def test_host_semantics_without_gpu():
     assert (bf.NMODEL, bf.NDIM) == (4, 5) and bf.fit_lnprob is None
     with pytest.raises(ValueError):
         bf.predict(np.zeros(4), np.zeros(4), logwt=np.zeros((2, 4)))
-    with pytest.raises(NotImplementedError):
-        bf.fit(np.ones((2, 5)), np.ones((2, 5)), np.ones((2, 5)), lprob_func=lambda *a: None)
+    # a user callable is the reference's plugin hook (bruteforce.py:193-194): called per object on the host
+    calls = []
+    def hook(x, xe, xm, ys, yes, yms, shift, scale=1.):
+        calls.append((x.shape, ys.shape, shift, scale))
+        lnl = -0.5 * np.square(ys - x).sum(axis=1) * scale
+        return np.full(len(ys), shift), lnl, lnl + shift, np.full(len(ys), 5), -2 * lnl
+    bf.fit(np.ones((2, 5)), np.ones((2, 5)), np.ones((2, 5)), lprob_func=hook, lprob_args=[0.25], lprob_kwargs={'scale': 2.}, verbose=False)
+    assert calls == [((5,), (4, 5), 0.25, 2.)] * 2 and bf.NDATA == 2
+    assert (bf.fit_lnprior == 0.25).all() and (bf.fit_lnprob == 0.25).all() and (bf.fit_Ndim == 5).all()
+    with pytest.raises(ValueError):
+        bf.fit(np.ones((2, 5)), np.ones((2, 5)), np.ones((2, 5)), lprob_func='not callable')
     with pytest.raises(NotImplementedError):
         like_opts({'bogus': 1})
     o = like_opts({'free_scale': True, 'ltol': 1e-6})
@@ -75,3 +84,64 @@ def test_host_semantics_without_gpu():
     d = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
     xi, si = d.fit(np.array([0.005, 0.015, 7.4]), np.array([-1., 0.0089999, 100.]))
     assert list(xi) == [0, 2, 740] and list(si) == [0, 1, 499]
+
+
+def test_product_pdfdict_against_golden_g3():
+    """the PRODUCT's ``frankenz_amd.PDFDict`` (pdf.py:778-852 of the reference) against the reference's own
+    tables and ``fit`` outputs (golden g3): grid metadata, integer half-widths, the ragged kernels and their
+    running sums (malformed wide entries included, by length), round-half-even / clamping of ``fit``."""
+    import numpy as np
+    from conftest import load_golden
+    from frankenz_amd import PDFDict
+    g = load_golden('g3_pdfdict')
+    d = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    eq = lambda a, b, rtol=0, atol=0: np.testing.assert_allclose(np.asarray(a, dtype=float), np.asarray(b, dtype=float), rtol=rtol, atol=atol)
+    assert d.Ngrid == int(g['Ngrid']) and d.Ndict == int(g['Ndict'])
+    eq(d.grid, g['grid']); eq(d.sigma_grid, g['sigma_grid']); eq(d.delta, g['delta']); eq(d.dsigma, g['dsigma'])
+    eq(d.min, g['grid'].min()); eq(d.max, g['grid'].max())
+    np.testing.assert_array_equal(d.sigma_width, g['sigma_width'])
+    assert d.sigma_width.dtype == g['sigma_width'].dtype
+    np.testing.assert_array_equal([len(k) for k in d.sigma_dict], g['lens'])
+    np.testing.assert_array_equal([len(k) for k in d.sigma_dict_cdf], g['lens'])
+    nf = int(g['nfull'])
+    eq(np.concatenate(d.sigma_dict[:nf]), g['kern'], rtol=1e-14)
+    eq(np.concatenate(d.sigma_dict_cdf[:nf]), g['kcdf'], rtol=1e-14)
+    eq([k.sum() for k in d.sigma_dict], g['kern_sum'], rtol=1e-13)
+    eq([k[0] if len(k) else np.nan for k in d.sigma_dict], g['kern_first'], rtol=1e-14)
+    eq([c[-1] if len(c) else np.nan for c in d.sigma_dict_cdf], g['kcdf_last'], rtol=1e-13)
+    xi, si = d.fit(g['fit_X'], g['fit_Xe'])
+    np.testing.assert_array_equal(xi, g['fit_xi']); np.testing.assert_array_equal(si, g['fit_si'])
+    assert xi.dtype == g['fit_xi'].dtype and si.dtype == g['fit_si'].dtype
+
+
+def test_network_lists_from_a_plane():
+    """host half of networks.populate_network (no GPU): the whole-plane segmented reductions against the
+    per-model walk of networks.py:310-354, for the weight threshold, the CDF rule and no threshold."""
+    import numpy as np
+    from scipy.special import logsumexp
+    from frankenz_amd.networks import _lists_from_plane
+    rs = np.random.RandomState(4)
+    Nm, Nn = 57, 23
+    lnp = -0.5 * rs.chisquare(3, size=(Nm, Nn)) * rs.choice([1., 8.], size=(Nm, 1))
+    sc, se = rs.uniform(0.5, 2, (Nm, Nn)), rs.uniform(0.01, 0.1, (Nm, Nn))
+    for wt, cdf, ts in ((1e-3, 2e-4, True), (None, 2e-2, True), (1e-12, 2e-4, False), (0.3, 2e-4, True)):
+        r = _lists_from_plane(lnp, sc, se, wt, cdf, ts)
+        idxs = [[] for _ in range(Nn)]; lw = [[] for _ in range(Nn)]; ss = [[] for _ in range(Nn)]; bm = [[] for _ in range(Nn)]
+        for i in range(Nm):
+            row = lnp[i]
+            bm[int(np.argmax(row))].append(i)
+            if wt is not None:
+                sel = np.arange(Nn)[row > np.log(wt) + row.max()]
+            else:
+                o = np.argsort(row); c = np.cumsum(np.exp(row - logsumexp(row))[o]); sel = o[c <= 1. - cdf]
+            lv = logsumexp(row[sel])
+            np.testing.assert_array_equal(r.results[i][0], sel)
+            np.testing.assert_allclose(r.results[i][1], row[sel] - lv, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(r.models_levid[i], lv, rtol=1e-13); assert r.models_lmap[i] == row[sel].max()
+            for j in sel:
+                idxs[j].append(i); lw[j].append(row[j] - lv); ss[j].append(sc[i, j] if ts else 1)
+        assert r.nodes_idxs == idxs and r.nodes_bmus == bm
+        np.testing.assert_array_equal(r.nodes_Nmatch, [len(a) for a in idxs])
+        for j in range(Nn):
+            np.testing.assert_allclose(r.nodes_logwts[j], lw[j], rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(r.nodes_scales[j], ss[j], rtol=0, atol=0)

@@ -129,3 +129,60 @@ def test_config3_full_size_one_million_objects():
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
     np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9); np.testing.assert_allclose(le[pick], rle, **EVID)
     np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
+
+
+def test_config4_knn_at_its_stated_shape(monkeypatch):
+    """BASELINE configs[3]: KMCkNN with the reference defaults K = 25, k = 20, luptitude features, on the
+    1e5-model set and 1e5 objects (knn.py:722-874) -- the regime where the screened fp32 search's admission
+    bound and the LDS hash de-duplication matter.  Properties on every row; the neighbour table, fits and
+    PDFs of a 60-object sample against the oracle's exact float64 search; the screened search against the
+    all-fp64 search on 20 000 objects."""
+    from frankenz_amd import NearestNeighbors
+    n, m = 100000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
+    Ye = 0.03 * Y + 0.1 * SDSS_SIGMA                       # a training set with its own photometric errors (demos/2 cell 73)
+    d, od = dicts()
+    fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9))
+    nn = NearestNeighbors(Y, Ye, Ym, K=25, feature_map='luptitude', fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(2), k=20, label_dict=d,
+                                 return_gof=True, verbose=False)
+    assert p.shape == (n, 701) and np.isfinite(p).all() and p.min() >= 0
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    W = 500
+    assert nn.neighbors.shape == (n, W) and nn.Nneighbors.min() >= 20 and nn.Nneighbors.max() <= W
+    col = np.arange(W)[None, :]
+    valid = col < nn.Nneighbors[:, None]
+    assert np.all(nn.neighbors[~valid] == -99) and nn.neighbors[valid].min() >= 0 and nn.neighbors[valid].max() < m
+    srt = np.sort(np.where(valid, nn.neighbors, -1 - col), axis=1)
+    assert np.all(np.diff(srt, axis=1) != 0)                                  # first-appearance de-duplication: no model twice in a row
+    assert np.all(np.isneginf(nn.fit_lnprob[~valid])) and np.all(le >= lm - 1e-12) and np.all(le <= lm + np.log(W) + 1e-9)
+    # oracle: exact float64 search over the same Monte-Carlo feature sets and query draws
+    pick = np.random.RandomState(3).choice(n, 60, replace=False)
+    feats = fo.knn_train(Y, Ye, 25, 'luptitude', np.random.RandomState(1), **fk)
+    q = fo.knn_query_features(X, Xe, 'luptitude', np.random.RandomState(2), **fk)
+    tab = fo.knn_neighbors_exact(feats, q[pick], 20)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, tab, z, ze, label_dict=od)
+    np.testing.assert_array_equal(nn.Nneighbors[pick], rnn)
+    np.testing.assert_array_equal(nn.neighbors[pick], rn)
+    np.testing.assert_allclose(nn.fit_lnprob[pick], rlnp, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(p[pick], rp, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-10); np.testing.assert_allclose(le[pick], rle, rtol=1e-10)
+    # screened (packed fp32 + exact re-check) search == all-fp64 search, bit for bit
+    sub = slice(40000, 60000)
+    nn2 = NearestNeighbors(Y, Ye, Ym, K=25, feature_map='luptitude', fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
+    monkeypatch.setenv('FZ_KNN_FP64', '1')
+    nn2.fit(X[sub].copy(), Xe[sub].copy(), Xm[sub].copy(), rstate=_Slice(np.random.RandomState(2), X, Xe, sub), k=20, verbose=False)
+    monkeypatch.delenv('FZ_KNN_FP64')
+    np.testing.assert_array_equal(nn2.neighbors, nn.neighbors[sub]); np.testing.assert_array_equal(nn2.Nneighbors, nn.Nneighbors[sub])
+
+
+class _Slice(object):
+    """RandomState stand-in: draws the Monte-Carlo realisation of the WHOLE catalogue (the stream of the
+    full call) and hands back the rows of a slice"""
+
+    def __init__(self, rs, X, Xe, sl):
+        self.draws = rs.normal(X, Xe)[sl]
+
+    def normal(self, loc, scale):
+        assert np.shape(loc) == self.draws.shape
+        return self.draws

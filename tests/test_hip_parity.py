@@ -723,3 +723,20 @@ def test_window_scatter_by_lane_or_by_wave(kde, monkeypatch):
     close(p0, p1, rtol=1e-10, atol=1e-16); close(lm0, lm1, rtol=0, atol=0); close(le0, le1, rtol=0, atol=0)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:30].copy(), Xe[:30].copy(), Xm[:30].copy(), Y, Ye, Ym, z, ze, **olab)
     close(p0[:30], rp, rtol=1e-8, atol=1e-14)
+
+
+def test_grid_kde_labels_above_the_grid_contribute_nothing():
+    """pdf.py:499-524: a label whose window lies wholly above the grid gives an empty slice, a zero sum,
+    and is skipped -- a valid reference input (model redshifts beyond the top of ``label_grid``), not an
+    error; a window that pokes in from above contributes its overlap.  Only windows wholly BELOW the
+    grid (negative upper bound: Python slicing wraps) stay refused."""
+    from frankenz_amd import pdf as hp
+    grid = np.arange(0, 7 + 1e-5, .01)
+    rs = np.random.RandomState(31)
+    y = np.concatenate([rs.uniform(0.2, 6.8, 40), [7.4, 9.0, 7.04, 25.0]])
+    ys = np.concatenate([rs.uniform(0.02, 0.2, 40), [0.05, 0.3, 0.03, 1.0]])
+    wt = rs.uniform(0.1, 1.0, len(y))
+    for kw in ({}, {'wt_thresh': 0.25}, {'sig_thresh': 3.}):
+        close(hp.gauss_kde(y, ys, grid, y_wt=wt, **kw), fo.gauss_kde(y, ys, grid, y_wt=wt, **kw), atol=1e-14)
+    with pytest.raises(IndexError):
+        hp.gauss_kde(np.array([-3.0, 1.0]), np.array([0.05, 0.05]), grid)

@@ -145,8 +145,8 @@ def test_prior_argument_errors():
         bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_func=logprob_prior(np.zeros((5, 100))), verbose=False)
     with pytest.raises(IndexError):                      # row index out of range
         bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_func=logprob_prior(np.zeros((5, 100)), np.full(12, 5)), verbose=False)
-    with pytest.raises(NotImplementedError):             # arbitrary callables still refuse loudly
-        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_func=lambda *a, **k: None, verbose=False)
+    with pytest.raises(NotImplementedError):             # a data-form prior takes keyword options only
+        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_func=logprob_prior(np.zeros(100)), lprob_args=[True], verbose=False)
     # a zero prior is the plain likelihood
     p0 = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, verbose=False, save_fits=False)
     p1 = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, lprob_func=logprob_prior(np.zeros(100)), label_dict=d,

@@ -115,3 +115,51 @@ def test_g11_network_map_golden(tag, kw, lk):
     np.testing.assert_allclose(cat(r.nodes_scales_err), g[tag + '_scales_err'], rtol=1e-10)
     bmu = np.array([[j for j in range(len(g['nodes'])) if i in r.nodes_bmus[j]][0] for i in range(len(g['models']))])
     np.testing.assert_array_equal(bmu, g[tag + '_bmu_of_model'])
+
+
+@pytest.mark.gpu
+def test_nz_assign_categorical_draw():
+    """SURVEY 8f-2, samplers.py:498-499 / 519-520: the per-object redshift assignment of the Gibbs sweeps.
+    (i) exact: bins and counts equal the oracle's NumPy inverse CDF on the same uniforms (a bin may differ
+    only where the target sits within rounding of a CDF edge -- across a plateau of empty bins, then); (ii) distribution: with many uniforms per
+    object the bin frequencies follow p * nz / dot(p, nz), the pvals of the reference's multinomial(1, .);
+    edge rows: all mass in one bin, a zero row (-1), u = 0 and u -> 1."""
+    from frankenz_amd import samplers
+    g = load_golden('g10_summarize')
+    pdfs = np.ascontiguousarray(g['pdfs_in'], dtype=np.float64)
+    pdfs = pdfs / pdfs.sum(axis=1)[:, None]
+    N, G = pdfs.shape
+    rs = np.random.RandomState(8)
+    nz = rs.dirichlet(np.full(G, 0.7))
+    reps = 400
+    big = np.tile(pdfs, (reps, 1))
+    u = rs.rand(len(big))
+    u[:N] = 0.0; u[N:2 * N] = 1.0 - 2.0 ** -53
+    big[-1] = 0.0                                            # a row without mass
+    counts, bins = samplers.nz_assign(nz, big, u=u, return_bins=True)
+    rc, rb, cdf = fo.nz_assign(nz, big, u)
+    diff = np.flatnonzero(bins != rb)
+    for i in diff:                                           # only at a CDF edge within rounding
+        t = u[i] * cdf[i, -1]
+        lo_, hi_ = min(bins[i], rb[i]), max(bins[i], rb[i])
+        assert abs(cdf[i, lo_] - t) <= 1e-12 * cdf[i, -1] and cdf[i, hi_ - 1] - cdf[i, lo_] <= 1e-12 * cdf[i, -1]
+    assert len(diff) <= 2 * N + 2 and bins[-1] == -1 and counts.sum() == len(big) - 1
+    np.testing.assert_array_equal(counts, np.bincount(bins[bins >= 0], minlength=G))
+    assert np.abs(counts - rc).sum() <= 2 * len(diff)
+    w = pdfs * nz
+    assert np.all(w[np.arange(N), bins[:N]] > 0) and np.all(w[np.arange(N), bins[N:2 * N]] > 0)      # u = 0 / u -> 1 land on mass
+    # distribution level: frequencies of object k's draws against its pvals (chi-square, 5-sigma bound)
+    pv = w / w.sum(axis=1)[:, None]
+    for k in (0, 3, N - 2):
+        b = bins[2 * N + k::N][:reps - 2]
+        obs = np.bincount(b, minlength=G).astype(float)
+        exp = pv[k] * len(b)
+        keep = exp > 5
+        chi2 = np.sum((obs[keep] - exp[keep]) ** 2 / exp[keep])
+        dof = keep.sum()
+        assert obs[pv[k] == 0].sum() == 0 and (dof == 0 or chi2 < dof + 5 * np.sqrt(2 * dof) + 10)
+    single = np.zeros((3, G)); single[:, 350] = 1.0
+    c1 = samplers.nz_assign(np.full(G, 1. / G), single, u=np.array([0., 0.5, 0.999999]))
+    assert c1[350] == 3 and c1.sum() == 3
+    with pytest.raises(ValueError):
+        samplers.nz_assign(nz, pdfs, u=np.full(N, 1.0))

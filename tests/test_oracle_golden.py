@@ -330,3 +330,25 @@ def test_g11_network_map(tag, kw, lk):
     eq(np.concatenate([np.array(v, dtype='float') for v in r['scales_err']]), g[tag + '_scales_err'])
     bmu = np.array([[j for j in range(len(g['nodes'])) if i in r['bmus'][j]][0] for i in range(len(g['models']))])
     np.testing.assert_array_equal(bmu, g[tag + '_bmu_of_model'])
+
+
+@pytest.mark.parametrize('tag', ['grid', 'train'])
+def test_g12_catalogue_stack(tag):
+    """configs[4] substitute: the oracle on the reference-simulated SDSS-like catalogue -- sampled PDFs,
+    ln-max / ln-evidence and the population ln-likelihood of the stack against the reference's outputs."""
+    g = load_golden('g12_catalogue_stack')
+    d = demo_dict()
+    obs, err = g['obs'], g['err']
+    pick = np.arange(0, 2000, 10)[:40]
+    if tag == 'grid':
+        Y, Ye, lab, lerr, kw = g['mphot'], np.zeros_like(g['mphot']), g['mz'], np.full(len(g['mz']), 0.03), dict(free_scale=True, ignore_model_err=True)
+    else:
+        Y, Ye, lab, lerr, kw = g['tr_obs'], g['tr_err'], g['tr_z'], np.full(len(g['tr_z']), 0.05), {}
+    p, lm, le = fo.bruteforce_fit_predict(obs[pick].copy(), err[pick].copy(), np.ones_like(obs[pick]), Y, Ye, np.ones_like(Y), lab, lerr,
+                                          label_dict=d, **kw)
+    eq(p, g[tag + '_pdfs_every10'][:40], rtol=1e-9, atol=1e-14)
+    eq(lm, g[tag + '_lmap'][pick], rtol=1e-11, atol=0); eq(le, g[tag + '_levid'][pick], rtol=1e-11, atol=0)
+    pd = g[tag + '_pdfs_every10']
+    stack = g[tag + '_stack']
+    ll, ov = fo.loglike_nz(stack / stack.sum(), pd)
+    eq(ov, g[tag + '_overlap_stack'][::10], rtol=1e-12, atol=0)
