@@ -239,6 +239,24 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     FZCHK(copy_in(c, c->d_cls.p, cls.data(), Mp * 4));
     FZCHK(copy_in(c, c->d_norm.p, nrm.data(), Mp * 8));
     c->single_cls = single; c->cls0 = (int32_t)hs[0]; c->w0 = (int32_t)c->h_widths[hs[0]];
+    if (single) {
+        // one dictionary kernel for every label: the edge-truncated mass (pdf.py:613-617) is a function of the
+        // grid index alone -- a table over the padded histogram row [0, G + 2 w0), entry q <-> index q - w0
+        const int64_t d = hs[0], w = c->h_widths[d], len = c->h_offsets[d + 1] - c->h_offsets[d];
+        const double* cdf = c->h_kcdf.data() + c->h_offsets[d];
+        std::vector<double> tab((size_t)(G + 2 * w), 1.0);
+        for (int64_t q = 0; q < G + 2 * w; ++q) {
+            const int64_t pp = q - w;
+            if (pp + w < 0 || pp - w > G - 1) continue;
+            const int64_t lo = std::max<int64_t>(pp - w, 0), hi = std::min<int64_t>(pp + w + 1, G);
+            const int64_t lpad = lo - (pp - w), hpad = hi - (pp + w + 1);
+            double mass = cdf[len + hpad - 1];
+            if (lpad != 0) mass -= cdf[lpad - 1];
+            tab[(size_t)q] = (mass > 0.0) ? mass : 1.0;
+        }
+        FZCHK(c->d_normtab.ensure(tab.size() * 8));
+        FZCHK(copy_in(c, c->d_normtab.p, tab.data(), tab.size() * 8));
+    }
     c->label_mode = 1; c->label_M = M;
     return 0;
 }

@@ -223,6 +223,7 @@ struct KdeView {
     const int32_t* pos;    // y_idx
     const int32_t* cls;    // y_std_idx
     const double* norm;    // edge-truncated kernel mass (pdf.py:613-617) / in-window sum (pdf.py:521)
+    const double* normtab; // KDE_HIST: the same mass as a function of the (padded) histogram index, [G + 2 w0]
     const int64_t* widths; const int64_t* offsets; const double* kern;
     int32_t w0; int64_t koff0;            // single sigma class: width and table offset
     // direct path (pdf.py:499-502, 519-524), per model
@@ -343,14 +344,17 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
 // HO: the caller's instantiation only ever sees the single-kernel (histogram) form.
 // scale: factor on the un-normalised output (the weight-space body stacks weights relative to its
 // own reference instead of the evidence; a normalised PDF does not see the difference)
+// bymass: the histogram holds plain weight sums per index; the division by the kernel mass of the
+// index (kv.normtab) happens here, once per index instead of once per stacked model.
 template <bool HO = false>
 __device__ __forceinline__ void kde_finalize(const KdeView& kv, double* row, bool ok, int normalize,
-                                             double* out, int lane, double scale = 1.0) {
+                                             double* out, int lane, double scale = 1.0, bool bymass = false) {
     const int G = (int)kv.G;
     if (!ok) { for (int t = lane; t < G; t += 64) out[t] = NAN; return; }
     double tot = 0.0;
     if (HO || kv.kmode == KDE_HIST) {
         const int w2 = 2 * kv.w0;
+        if (bymass) { for (int k = lane; k < G + w2; k += 64) row[k] = row[k] / kv.normtab[k]; }
         const double* kr = kv.kern + kv.koff0;
         if (w2 < 128) {
             // the dictionary kernel (w2 + 1 taps) sits in two registers across the wave -- one coalesced
@@ -674,7 +678,9 @@ __device__ __forceinline__ void w_rebase(const SRC& src, WState<TW>& ws, int o, 
     }
 }
 
-template <class SRC, int TW, bool TAIL, int TL>
+// POSW: the tile carries the models' histogram indices (int32 words behind the records) and a candidate
+// records ITS index instead of its model number: the PDF stage then needs no label gathers.
+template <class SRC, int TW, bool TAIL, int TL, bool POSW>
 __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb, const double* cur, const double* objs,
                                              int jt0, int M, int lane, float thrf, Cand* buf, int64_t cap,
                                              WState<TW>& ws) {
@@ -695,6 +701,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
         const int j = jt0 + s * 64 + lane;
         typename SRC::MR m;
         src.template load_model_lds<TL>(cur, s * 64 + lane, m);
+        const int tag = POSW ? reinterpret_cast<const int32_t*>(cur + SRC::RW * TL)[s * 64 + lane] : j;     // what a candidate records
         double c2[TW];
         float t[TW];
         bool over = false;
@@ -718,7 +725,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
                     const float l2 = __builtin_amdgcn_logf((float)c2[o] * ws.rcr[o]);
                     t[o] = fmaf(l2, 0.5f * WP, fmaf(dcf, -0.72134752f, ws.kp[o]));
                     const bool big = !(t[o] <= 60.f);         // still out of range (every weight of the step is <= ~1 now): exact treatment
-                    append(o, big, c2[o], j);
+                    append(o, big, c2[o], tag);
                     t[o] = big ? -INFINITY : t[o];            // ... and no weight in the loop
                 }
             }
@@ -729,7 +736,7 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
             ws.wmax[o] = fmaxf(ws.wmax[o], w);
             const bool c = w > ws.wmax[o] * thrf;
             if (!c) ws.s[o] += w;                                    // candidates are summed exactly by the PDF stage
-            append(o, c, c2[o], j);
+            append(o, c, c2[o], tag);
         }
         ++ws.tick;
         if ((ws.tick & 15) == 0) {
@@ -761,7 +768,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     // wait for the copy of the next), the per-object results a wave parks, the log / exp tables, the
     // parked object rows.  Outside the model loop the tile buffers hold the waves' PDF rows (half
     // of the waves in each); grids too long for that get dynamic LDS for the rows instead.
-    constexpr int TILE = SRC::template tile_len<NW>(), TD = SRC::template tile_doubles<TILE>(), NCH = TD / 2, NT = NW * 64;
+    constexpr bool POSW = WM && HO;                               // weight-space body + one dictionary kernel: index words ride in the tile
+    constexpr int TILE = SRC::template tile_len<NW>(), TDR = SRC::template tile_doubles<TILE>(), TD = TDR + (POSW ? TILE / 2 : 0);
+    constexpr int NCH = TD / 2, NT = NW * 64;
     constexpr int CPT = (NCH + NT - 1) / NT;                      // staging chunks per thread
     constexpr int OD = SRC::OBJ_DOUBLES;
     constexpr int HW = (NW + 1) / 2;                              // waves whose rows share a tile buffer
@@ -788,6 +797,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     src.tb = stage_tabs(tabs, tid, NT);
     const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
+    const int32_t* posw = POSW ? kvp->pos : nullptr;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
     const float thrf = uniform_f((wt_thresh > 0.0) ? (float)(wt_thresh * 0.99) : 0.f);          // fp32 screen: a 1 % margin below the exact threshold
     const double lthr = (wt_thresh > 0.0) ? log(wt_thresh) : -INFINITY;
@@ -816,14 +826,25 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
         // weight-space body keeps register staging (loads issued before, parked after the
         // compute of the current tile), which measured 2-4 % faster there.
         constexpr bool GLDS = true;       // (register staging measured 2-4 % faster for the old fp64 weight-space body; the fp32-tail body spills it)
-        auto stage_tile = [&](int tile, double* dstbuf) {
+        // LDS-DMA copy of one tile: its segments (records | mask words | index words) are contiguous in
+        // HBM and in LDS, so each is a run of 1-KB wave-instructions; the source address is a wave-uniform
+        // base plus the thread's 16-byte slot, which keeps one 32-bit offset register live instead of a
+        // 64-bit pointer per chunk (those spilled, and every reload made the copies wait for each other)
+        auto stage_seg = [&](const void* base, int nchunks, double* dst) {
+            const uint32_t slot = (uint32_t)tid * 16u;
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                const int ch = tid + q * NT;
-                if (ch < NCH)
-                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src.template tile_chunk_ptr<TILE>(tile, ch),
-                                                     (lds_void*)(dstbuf + 2 * (q * NT + wave * 64)), 16, 0, 0);
+            for (int q = 0; q < (nchunks + NT - 1) / NT; ++q) {
+                if (tid + q * NT < nchunks)
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)(reinterpret_cast<const char*>(base) + (size_t)q * NT * 16 + slot),
+                                                     (lds_void*)(dst + 2 * (q * NT + wave * 64)), 16, 0, 0);
             }
+        };
+        auto stage_tile = [&](int tile, double* dstbuf) {
+            constexpr int NREC = SRC::RW * TILE / 2;                 // 16-byte chunks of the records
+            const double* rec = (SRC::LMODE == 0) ? src.mv.rec0 : src.mv.rec1;
+            stage_seg(rec + (int64_t)tile * (TILE * SRC::RW), NREC, dstbuf);
+            if constexpr (TDR > SRC::RW * TILE) stage_seg(src.mv.bits + (int64_t)tile * TILE, TILE / 4, dstbuf + SRC::RW * TILE);
+            if constexpr (POSW) stage_seg(posw + (int64_t)tile * TILE, TILE / 4, dstbuf + TDR);
         };
         double2 stage[CPT];
         if (GLDS) {
@@ -847,8 +868,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
             }
             if (work && WM) {
                 if constexpr (WM) {
-                    if (more) fused_tile_w<SRC, TW, false, TILE>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
-                    else fused_tile_w<SRC, TW, true, TILE>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    if (more) fused_tile_w<SRC, TW, false, TILE, POSW>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
+                    else fused_tile_w<SRC, TW, true, TILE, POSW>(src, tb, cur, objs, t * TILE, M, lane, thrf, buf, cap, ws);
                 }
             } else if (work) {                                    // unswitched on (dim_prior, last tile)
                 if (more) {
@@ -912,7 +933,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 // A wave walks its object's list alone, so each trip is two dependent memory
                 // round trips (the entries, then the labels of the selected ones): U 64-entry
                 // blocks are kept in flight per trip to overlap them.
-                constexpr int U = (HO && !WM) ? 8 : 4;
+                constexpr int U = HO ? 8 : 4;
                 if constexpr (WM) {
                     // Candidates carry their fp64 chi2.  One walk: exact ln-like, exact maximum, the
                     // candidates' exact share of the evidence, and the stack -- weights relative to the
@@ -939,7 +960,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                             sel[u] = in[u] && (d > lthr + DEL);
                             anyamb |= in[u] && !sel[u] && (d >= lthr - DEL);
                         }
-                        if (HO || kv.kmode == KDE_HIST) {
+                        if (HO) {                 // entries carry the histogram index; the division by the kernel mass waits for the finalize
+#pragma unroll
+                            for (int u = 0; u < U; ++u) if (sel[u]) unsafeAtomicAdd(&row[e[u].j + kv.w0], w[u]);
+                        } else if (kv.kmode == KDE_HIST) {
                             int p[U]; double nr[U];
 #pragma unroll
                             for (int u = 0; u < U; ++u) { const int j = sel[u] ? e[u].j : 0; p[u] = kv.pos[j]; nr[u] = kv.norm[j]; }
@@ -964,7 +988,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                             const bool amb = in1 && !(d > lthr + DEL) && (d >= lthr - DEL);
                             const bool s1 = amb && (exp_neg(l - le, tb) > thr);          // strict, pdf.py:510/591
                             const double w1 = exp_neg(l - ref, tb);
-                            if (HO || kv.kmode == KDE_HIST) {
+                            if (HO) {
+                                if (s1) unsafeAtomicAdd(&row[e1.j + kv.w0], w1);
+                            } else if (kv.kmode == KDE_HIST) {
                                 if (s1) unsafeAtomicAdd(&row[kv.pos[e1.j] + kv.w0], w1 / kv.norm[e1.j]);
                             } else kde_scatter(kv, row, s1, w1, e1.j, lane);
                         }
@@ -977,7 +1003,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                         if (levid) levid[i] = le;
                         if (!ok) redo[1 + atomicAdd(redo, 1)] = (int)i;
                     }
-                    kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane, exp_neg(ref - le, tb));
+                    kde_finalize<HO>(kv, row, ok, normalize, pdfs + i * kv.G, lane, exp_neg(ref - le, tb), HO);
                 } else {
                 const double lm = res[o * FZ_RES + 0], le = res[o * FZ_RES + 1], mx = res[o * FZ_RES + 2];
                 if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }

@@ -17,6 +17,7 @@ inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
         kv.widths = c->d_widths.as<int64_t>(); kv.offsets = c->d_offsets.as<int64_t>(); kv.kern = c->d_kern.as<double>();
         kv.w0 = c->w0; kv.koff0 = c->h_offsets[c->cls0];
         kv.kmode = c->single_cls ? KDE_HIST : KDE_DICT;
+        kv.normtab = c->single_cls ? c->d_normtab.as<double>() : nullptr;
         kv.acc_stride = (int)(kv.kmode == KDE_HIST ? c->G + 2 * c->w0 : c->G);
     } else {
         kv.ly = c->d_ly.as<double>(); kv.lstd = c->d_lstd.as<double>(); kv.lo = c->d_lo.as<int32_t>(); kv.hi = c->d_hi.as<int32_t>();
@@ -113,7 +114,8 @@ template <class SRC, int TW, int NW, bool WM>
 int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
     // the PDF rows live inside the (static) tile buffers when half of the waves' rows fit in one, else in dynamic LDS
-    constexpr size_t TDB = (size_t)SRC::template tile_doubles<SRC::template tile_len<NW>()>();
+    const size_t TDB = (size_t)SRC::template tile_doubles<SRC::template tile_len<NW>()>() +
+                       ((WM && kv.kmode == fz::KDE_HIST) ? SRC::template tile_len<NW>() / 2 : 0);       // + the index words (k_fused, POSW)
     const size_t lds = ((size_t)((NW + 1) / 2) * kv.acc_stride <= TDB) ? 0 : (size_t)NW * kv.acc_stride * 8;
     auto kern = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, TW, NW, WM, true> : fz::k_fused<SRC, TW, NW, WM, false>;
     {
