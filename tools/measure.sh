@@ -2,9 +2,13 @@
 # Full measurement set for profiles/ (run through gpurun; writes gpurun_out/m_*).
 #   ./tools/measure.sh
 export TMPDIR=/tmp
+export FZ_BENCH_NO_EXTRA=1
 O=gpurun_out
 mkdir -p $O
-python3 bench.py > $O/m_bench_fit_predict_modeA.json 2> $O/m_bench_fit_predict_modeA.err
+FZ_BENCH_NO_EXTRA= python3 bench.py > $O/m_bench_fit_predict_modeA.json 2> $O/m_bench_fit_predict_modeA.err
+FZ_NO_WSPACE=1 FZ_BENCH_NO_EXTRA=1 python3 bench.py --no-cpu > $O/m_bench_fit_predict_modeA_all_fp64_body.json 2>/dev/null
+python3 bench.py --noise-scale 3 --nobj 262144 --no-cpu > $O/m_bench_fit_predict_noise3.json 2>/dev/null
+python3 bench.py --noise-scale 10 --nobj 262144 --no-cpu > $O/m_bench_fit_predict_noise10.json 2>/dev/null
 python3 bench.py --model-err varying --no-cpu > $O/m_bench_fit_predict_modeA_varying_model_errors.json 2>/dev/null
 python3 bench.py --mode B --no-cpu > $O/m_bench_fit_predict_modeB.json 2>/dev/null
 python3 bench.py --mode Ai --no-cpu > $O/m_bench_fit_predict_modeAi.json 2>/dev/null

@@ -3,6 +3,7 @@
 # sys/hip traces).  Writes gpurun_out/pmc_<n>/ and prints per-kernel per-launch sums.
 #   BENCH_ARGS="--mode B" ./tools/pmc.sh
 export TMPDIR=/tmp
+export FZ_BENCH_NO_EXTRA=1
 ARGS="--nobj ${NOBJ:-262144} --nmodel 100000 --steps 1 --warmup 1 --no-cpu ${BENCH_ARGS}"
 SETS=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"

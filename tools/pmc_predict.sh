@@ -2,6 +2,7 @@
 # PMC passes for the predict-from-plane kernels (separate runs, kernel-trace only).
 #   ./tools_pmc_predict.sh            (NOBJ / NMODEL override the 1e5 x 1e4 plane)
 export TMPDIR=/tmp
+export FZ_BENCH_NO_EXTRA=1
 ARGS="--workload predict --nobj ${NOBJ:-100000} --nmodel ${NMODEL:-10000} --steps 1 --warmup 1 --no-cpu"
 SETS=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"

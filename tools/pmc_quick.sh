@@ -2,6 +2,7 @@
 # three SQ counter passes of the bench kernel (kernel-trace only), per-launch sums printed
 #   BENCH_ARGS="--mode B" NOBJ=262144 ./tools/pmc_quick.sh tag
 export TMPDIR=/tmp
+export FZ_BENCH_NO_EXTRA=1
 TAG=${1:-q}
 ARGS="--nobj ${NOBJ:-262144} --nmodel 100000 --steps 1 --warmup 1 --no-cpu ${BENCH_ARGS}"
 SETS=(
