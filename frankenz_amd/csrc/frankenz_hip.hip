@@ -496,7 +496,7 @@ static int modec_final(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o,
     SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
     const int64_t Mloc = nbr ? W : c->M;
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
-    st.sh = c->d_mc[3].as<double>(); st.err = nullptr; st.firstnan = nullptr; st.list = nullptr; st.list_next = nullptr; st.nactive = nullptr;
+    st.sh = c->d_mc[3].as<double>(); st.err = nullptr; st.firstnan = nullptr; st.list = nullptr; st.list_next = nullptr; st.nactive = nullptr; st.ncur = nullptr; st.last_iter = nullptr;
     const int64_t tot = n * Mloc;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
     hipLaunchKernelGGL(k_modec_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, st, model_view(c), sub,

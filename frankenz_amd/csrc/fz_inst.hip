@@ -92,30 +92,45 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     if (n > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.firstnan = c->d_mcfn.as<int>();
-    int* lists[2] = {c->d_mcact.as<int>(), c->d_mcact.as<int>() + n};        // active objects: this launch / the next
-    st.list = nullptr; st.list_next = lists[0]; st.nactive = c->d_mccnt.as<int>();
+    // Active-object lists and their lengths live on the device and alternate between two slots; the host
+    // queues FZ_MODEC_BURST iterations (step + stop rule, launched for the object count it last saw: blocks
+    // of objects that stopped since exit at once) before it looks at the count again, so the loop is not
+    // paced by one host round trip per iteration (a quarter of the time before).
+    int* lists[2] = {c->d_mcact.as<int>(), c->d_mcact.as<int>() + n};
+    int* counts = c->d_mccnt.as<int>();                  // [0], [1]: list lengths; [2]: last iteration that left objects active
+    HIPCHK(hipMemsetAsync(counts, 0, 16, c->stream));
     HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
     HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
+    st.list = nullptr; st.ncur = nullptr; st.list_next = lists[0]; st.nactive = counts; st.last_iter = counts + 2;
     ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B; mc.sub = sub;
     const int64_t tiles = (M + 255) / 256;
     if (n * tiles > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
+    const int burst = getenv("FZ_MODEC_BURST") ? std::max(1, atoi(getenv("FZ_MODEC_BURST"))) : 8;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
     hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(n * tiles)), dim3(256), 0, c->stream, mc, st, n, M, 1);
-    int it = 0, nact = (int)n;        // every object takes the first iteration
+    // iteration 0 runs on every object (list == nullptr); iteration t >= 1 on list t & 1 ... written by the check of t - 1
+    int it = 0, nact = (int)n;        // nact: an upper bound of the active count
+    bool first = true;
     while (nact > 0) {
         if (it >= max_iter)
             return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
                             "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
-        HIPCHK(hipMemsetAsync(st.nactive, 0, 4, c->stream));
-        hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(nact * tiles)), dim3(256), 0, c->stream, mc, st, nact, M, 0);
-        hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((nact + 255) / 256)), dim3(256), 0, c->stream, st, nact, o->ltol);
-        HIPCHK(hipMemcpyAsync(&nact, st.nactive, 4, hipMemcpyDeviceToHost, c->stream));
+        for (int b = 0; b < burst && it < max_iter; ++b, ++it) {
+            const int cur = it & 1, nxt = cur ^ 1;
+            st.list = first ? nullptr : lists[cur]; st.ncur = first ? nullptr : counts + cur;
+            st.list_next = lists[nxt]; st.nactive = counts + nxt;
+            HIPCHK(hipMemsetAsync(counts + nxt, 0, 4, c->stream));
+            hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(nact * tiles)), dim3(256), 0, c->stream, mc, st, nact, M, 0);
+            hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((nact + 255) / 256)), dim3(256), 0, c->stream, st, nact, o->ltol, it + 1);
+            first = false;
+        }
+        HIPCHK(hipMemcpyAsync(&nact, counts + (it & 1), 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        st.list = st.list_next;                                       // survivors, in arrival order
-        st.list_next = lists[(it + 1) & 1];
-        ++it;
     }
+    HIPCHK(hipMemcpyAsync(&it, counts + 2, 4, hipMemcpyDeviceToHost, c->stream));      // iterations the slowest object took, minus one
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ++it;
     c->tm.n_modec += it;             // iterations of the slowest object of the chunk (+1 per timed scope: the initial pass)
     HIPCHK(hipGetLastError());
     return 0;

@@ -27,6 +27,8 @@ struct ModeCState {
     const int* list;           // objects this launch advances (nullptr: all Nc), written by the last check
     int* list_next;            // objects that go on (filled by k_modec_check)
     int* nactive;              // (1) length of list_next
+    const int* ncur;           // (1) length of `list` on the device (nullptr: Nc): the host launches for an upper bound
+    int* last_iter;            // (1) highest iteration after which some object still went on
 };
 
 // Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
@@ -80,7 +82,8 @@ struct ModeC {
 template <class MC>
 __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_t Nc, int64_t M, int init) {
     const int64_t tiles = (M + 255) / 256;
-    const int64_t slot = blockIdx.x / tiles;             // Nc = number of objects of this launch
+    const int64_t slot = blockIdx.x / tiles;             // Nc = number of objects of this launch (an upper bound when st.ncur is set)
+    if (st.ncur && slot >= *st.ncur) return;             // block-uniform: this slot's object stopped since the host last looked
     const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
     const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
     const bool valid = j < M && (!mc.sub.nnb || j < mc.sub.nnb[i]);
@@ -112,14 +115,14 @@ __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_
     }
 }
 
-static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol) {
+static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol, int iter) {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= Nc) return;
+    if (slot >= Nc || (st.ncur && slot >= *st.ncur)) return;
     const int i = st.list ? st.list[slot] : (int)slot;
     const double e = __longlong_as_double((long long)st.err[i]);
     const bool go = !st.firstnan[i] && (e > ltol);       // `while lerr > ltol`
     st.err[i] = 0ull;
-    if (go) st.list_next[atomicAdd(st.nactive, 1)] = i;
+    if (go) { st.list_next[atomicAdd(st.nactive, 1)] = i; atomicMax(st.last_iter, iter); }
 }
 
 // after convergence: dim prior (pdf.py:226-229) and the output planes
