@@ -6,6 +6,7 @@
 #include "fz_kernels.h"
 #include "fz_cdf.h"
 #include "fz_knn.h"
+#include "fz_knn_mfma.h"
 #include "fz_launch.h"
 #include "fz_modec.h"
 #include "fz_summary.h"

@@ -1,0 +1,285 @@
+// Euclidean k-nearest-neighbour search on the matrix pipe (reference: the K scipy KDTree.query
+// calls of knn.py:834-837; SURVEY 7 hard part 5).
+//
+// With q' = fl32(q - c) for a per-set centre c, the squared distance of a query and a model is one
+// 8-slot row-times-column product (F <= 6)
+//     |q' - (p - c)|^2 = [-2 q'_0 .. -2 q'_{F-1}, alpha, 1, 0 ..] . [p_0 .. p_{F-1}, 1, beta, 0 ..]
+//     alpha = |q'|^2 + 2 q'.c      beta = |p - c|^2            (both formed in fp64, rounded once)
+// so a wave forms the 16 x 16 distances of 16 queries and 16 models with two
+// v_mfma_f32_16x16x4_f32 (32 cycles each: 4 distances per cycle and SIMD, against ~1.5 for the
+// packed-fp32 vector form of fz_knn.h).  The model side holds the ORIGINAL float features, so the
+// LDS tile that feeds the matrix pipe also feeds the exact re-check; the centring only lives in
+// alpha / beta and keeps the big |q|^2 + |p|^2 - 2 q.p cancellation out of the fp32 chain.
+// The product is only the SCREEN: it is compared with an admission bar that is provably above the
+// exact k-th distance (bound below), and the pairs that pass recompute their distance in fp64 from
+// the original query and features and go through the same sorted-list insertion as k_knn_query --
+// the neighbour table is the exact fp64 top-k, bit for bit (tests/test_hip_knn.py
+// test_screened_search_is_the_exact_search, tests/test_hip_fullsize.py at M = 1e5, K = 25, k = 20).
+//
+// Bar.  u = 2^-24, Q = |q'|, P = max_p |p - c|, C = |c|.  Without rounding the product is
+// |q' - (p - c)|^2 + e_a alpha + e_b beta (|e| <= u), and | |q' - (p - c)| - |q - p| | <= u Q; the 8-term
+// fma chain of the matrix pipe adds at most 8 u sum |a_k b_k| <= 8 u (2 Q (P + C) + |alpha| + beta) (16 u is
+// budgeted, in case the pipe truncates).  Hence  |q - p|^2 < tau  implies
+//     fl(product) < tau + 2 sqrt(tau) u Q + u (18 Q^2 + 18 P^2 + 68 Q C + 32 Q P),
+// which (slack terms times 1.01, every float operation rounded up) is the bar.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fz {
+
+typedef float fz_f4 __attribute__((ext_vector_type(4)));
+
+#define FZ_KM_TILE 128                  // models per LDS tile
+#define FZ_KM_TFLOATS (FZ_KM_TILE * 8)  // 8 slots per model
+
+// per-feature mean of one feature set (one block per set), in fp64
+static __global__ __launch_bounds__(256) void k_knn_center(const float* __restrict__ in, int64_t M, int F, float* __restrict__ cen) {
+    const int t = blockIdx.x;
+    __shared__ double sh[256];
+    for (int f = 0; f < 8; ++f) {
+        double s = 0.0;
+        if (f < F) for (int64_t j = threadIdx.x; j < M; j += 256) s += (double)in[((size_t)t * M + j) * F + f];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+        if (threadIdx.x == 0) cen[t * 8 + f] = (f < F) ? (float)(sh[0] / (double)M) : 0.f;
+        __syncthreads();
+    }
+}
+
+// B operands: [set][64-model block][half kb][lane][group g] floats -- lane l of the wave reads, for the
+// four 16-model groups of a 64-model step, slot kb*4 + (l >> 4) of model 16 g + (l & 15) as ONE 16-byte
+// LDS read.  Slots: p_f (f < F, the original float), 1 (slot F), beta (slot F+1), 0.  Pad models: beta = 1e30.
+static __global__ __launch_bounds__(256) void k_knn_pack_mfma(const float* __restrict__ in, int64_t M, int F, int64_t Mp,
+                                                              const float* __restrict__ cen, float* __restrict__ bmat,
+                                                              unsigned* __restrict__ pmax_bits) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j >= Mp) return;
+    float slot[8];
+    for (int f = 0; f < 8; ++f) slot[f] = 0.f;
+    if (j < M) {
+        double n2 = 0.0;
+        for (int f = 0; f < F; ++f) {
+            slot[f] = in[((size_t)t * M + j) * F + f];
+            const double pc = (double)slot[f] - (double)cen[t * 8 + f];
+            n2 = fma(pc, pc, n2);
+        }
+        slot[F] = 1.f; slot[F + 1] = (float)n2;
+        atomicMax(&pmax_bits[t], __float_as_uint((float)(sqrt(n2) * 1.000001)));     // positive floats order like their bits
+    } else {
+        slot[F] = 1.f; slot[F + 1] = 1e30f;
+    }
+    const int64_t blk = j >> 6; const int m = (int)(j & 63), g = m >> 4, col = m & 15;
+    float* o = bmat + ((size_t)t * (Mp >> 6) + blk) * 512;
+    for (int s = 0; s < 8; ++s) o[(s >> 2) * 256 + ((s & 3) * 16 + col) * 4 + g] = slot[s];
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float f32_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }     // x > 0 finite
+// bar of a row: tau (fp64 k-th distance or the squared bound), uq2 = 2 u Q, e = u (19 Q^2 + ...) of the header
+__device__ __forceinline__ float knn_bar_mfma(double tau, float uq2, float e) {
+    if (!(tau < 1e37)) return INFINITY;
+    float t = (float)tau;
+    if ((double)t < tau) t = f32_up(t);
+    const float slack = 1.01f * fmaf(uq2, 1.00001f * __builtin_amdgcn_sqrtf(t), e);      // raw v_sqrt_f32: 1 ulp, covered by the factor
+    return f32_up(f32_up(fmaf(t, 1.000002f, slack)));                                     // the 17 u bar term of the header
+}
+
+// 4 waves x 16 queries per block, one feature set per blockIdx.y (+ tree0); the block streams the set's
+// models through two LDS tiles (separate arrays: the LDS-DMA of the next tile does not stall the reads
+// of the current one).
+//  * The bar of a query row is folded INTO the product (slot F holds alpha - bar), so the screen of a
+//    64-model step is the sign of 16 accumulators: 8 v_or3 and one compare next to the 8 MFMAs.
+//  * The sorted top-k lists of the 16 queries of a wave live in LDS (dynamic: [wave][16 rows][kpad] fp64
+//    distances, then the int32 indices), ordered by (distance, model index) -- the order an ascending
+//    scan with first-come ties leaves, whatever the arrival order -- so the admission path is one rolled
+//    loop over the pairs that passed the screen.
+//  * seed (may be null): the neighbour table of feature set 0, already complete.  The K feature sets
+//    are noise realisations of the SAME models, so the k neighbours found in set 0 are k distinct
+//    models that are close in this set too: their exact distances start the list, and the bar starts
+//    at their largest instead of +inf -- the k ln(M / k) admissions of a cold scan (half of them in
+//    the first 1 % of the models) shrink to the few models that really sit inside that ball.
+// FX: the feature count when it is a compile-time constant (5: the usual five bands), 0 = runtime F.
+template <int TILE, int FX>
+static __global__ __launch_bounds__(256) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
+                                                         const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
+                                                         int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
+                                                         int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed) {
+    constexpr int TF = TILE * 8;
+    constexpr int FL = FX ? FX : 6;                    // feature loop bound of the exact re-check
+    __shared__ __attribute__((aligned(16))) float tA[TF];
+    __shared__ __attribute__((aligned(16))) float tB[TF];
+    __shared__ double qs[4][16][8];                   // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
+    extern __shared__ double s_lists[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tree = blockIdx.y + tree0;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    const float* bm = bmat + (size_t)tree * (Mp >> 6) * 512;
+    const int row = lane & 15, sl = lane >> 4;
+    double* Ld = s_lists + (size_t)wave * 16 * kpad;                                     // [16][kpad]
+    int* Lj = reinterpret_cast<int*>(s_lists + (size_t)4 * 16 * kpad) + (size_t)wave * 16 * kpad;
+    for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
+    // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
+    {
+        const int64_t i = i0 + row < N ? i0 + row : N - 1;
+        for (int ff = sl; ff < 6; ff += 4) qs[wave][row][ff] = (ff < F) ? q[i * F + ff] : 0.0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): own LDS writes done (the same wave reads them)
+    float qc[6]; double qn2 = 0.0, qdc = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const double cf = (f < F) ? (double)cen[tree * 8 + f] : 0.0;
+        qc[f] = (f < F) ? (float)(qs[wave][row][f] - cf) : 0.f;
+        qn2 = fma((double)qc[f], (double)qc[f], qn2); qdc = fma((double)qc[f], cf, qdc); c2 = fma(cf, cf, c2);
+    }
+    const float alpha = (float)(qn2 + 2.0 * qdc);
+    {
+        const double u = 6.0e-8, Q = sqrt(qn2) * 1.000001, P = (double)pmax[tree], C = sqrt(c2) * 1.000001;
+        const float uq2 = (float)(2.0 * u * Q * 1.000001);
+        const float e = (float)(u * (19.0 * Q * Q + 18.0 * P * P + 70.0 * Q * C + 32.0 * Q * P) * 1.000001);
+        if (sl == 0) { float2 pk; pk.x = uq2; pk.y = e; *reinterpret_cast<float2*>(&qs[wave][row][7]) = pk; qs[wave][row][6] = bound2; }
+    }
+    // ---- seeds: exact distances of set 0's neighbours in THIS set, ranked into the row's list ----
+    if (seed) {
+        const float* ft = feats + (size_t)tree * FT * Mp;
+        for (int R = 0; R < 16; ++R) {
+            const int64_t i = i0 + R < N ? i0 + R : N - 1;
+            const int64_t js64 = (lane < k) ? seed[(i * K) * k + lane] : (int64_t)M;
+            const bool valid = js64 >= 0 && js64 < M;
+            int js = valid ? (int)js64 : M + lane;                          // distinct keys for the empty entries
+            double d2 = INFINITY;
+            if (valid) {
+                d2 = 0.0;
+                for (int f = 0; f < F; ++f) { const double d = qs[wave][R][f] - (double)ft[(size_t)f * Mp + js]; d2 = fma(d, d, d2); }
+                if (!(d2 < bound2)) { d2 = INFINITY; js = M + lane; }
+            }
+            double* ldr = Ld + R * kpad; int* ljr = Lj + R * kpad;
+            if (lane < k) { ldr[lane] = d2; ljr[lane] = js; }
+            int rank = 0;
+            for (int m = 0; m < k; ++m) { const double dm = ldr[m]; const int jm = ljr[m]; rank += (dm < d2 || (dm == d2 && jm < js)) ? 1 : 0; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane < k) { ldr[rank] = d2; ljr[rank] = js; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane < 16) { const double kd = Ld[lane * kpad + k - 1]; qs[wave][lane][6] = kd < bound2 ? kd : bound2; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    // A operands: slots -2 q'_f | alpha - bar | 1 | 0; the bar slot F sits in a0 (F < 4) or a1 of the lanes with sl == F & 3
+    auto aslot = [&](int s, float ab) -> float {
+        float v = (s == F) ? ab : ((s == F + 1) ? 1.f : 0.f);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) if (s == f && f < F) v = -2.f * qc[f];
+        return v;
+    };
+    float a0, a1;
+    {
+        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
+        const float ab = alpha - knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
+        a0 = aslot(sl, ab); a1 = aslot(4 + sl, ab);
+    }
+    const bool bar_lane = sl == (F & 3);
+
+    const int ntiles = (M + TILE - 1) / TILE;
+    auto stage = [&](int tile, float* dst) {             // contiguous: 1-KB wave-instructions
+        const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
+#pragma unroll
+        for (int c = 0; c < TF * 4 / (256 * 16); ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 4096 + (uint32_t)tid * 16u),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024 + wave * 256), 16, 0, 0);
+    };
+    // admission path.  pm: this lane's 16-bit mask of (g, r) products under the bar.
+    auto slow = [&](unsigned pm, const float* blk, int jb) {
+        while (__any(pm != 0u)) {
+            // every lane with something left takes its lowest pair: query row 4 sl + r, model 16 g + col of the step
+            const bool has = pm != 0u;
+            const int e = has ? __builtin_ctz(pm) : 0;
+            pm &= pm - 1u;
+            const int g = e >> 2, r = e & 3, R = 4 * sl + r;
+            const int j = jb + 16 * g + row;
+            double qv[FL]; float pv[FL];                             // exact distance from the original query and features
+#pragma unroll
+            for (int f = 0; f < FL; ++f) { qv[f] = qs[wave][R][f]; pv[f] = blk[(f >> 2) * 256 + ((f & 3) * 16 + row) * 4 + g]; }
+            const double taur = qs[wave][R][6];
+            double d2 = 0.0;
+#pragma unroll
+            for (int f = 0; f < FL; ++f) { const double d = (FX || f < F) ? qv[f] - (double)pv[f] : 0.0; d2 = fma(d, d, d2); }
+            unsigned long long cm = __ballot(has && j < M && d2 <= taur && d2 < bound2);
+            while (cm) {                                             // one candidate at a time into its row's sorted list
+                const int s1 = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const double dn = readlane_d(d2, s1);                // wave-uniform: scalar registers, no LDS round trip
+                const int Rn = __builtin_amdgcn_readlane(R, s1), jn = __builtin_amdgcn_readlane(j, s1);
+                double* ldr = Ld + Rn * kpad; int* ljr = Lj + Rn * kpad;
+                // everything the insertion needs, in one LDS round trip
+                double l = ldr[lane < k ? lane : 0];
+                int lj = ljr[lane < k ? lane : 0];
+                double pk2 = ldr[k > 1 ? k - 2 : 0];
+                float2 pk = *reinterpret_cast<const float2*>(&qs[wave][Rn][7]);
+                asm volatile("" : "+v"(l), "+v"(lj), "+v"(pk2), "+v"(pk.x), "+v"(pk.y));     // all loads in flight before anything is consumed
+                // lexicographic (distance, index) order; a model already listed (a seed) is not listed twice
+                const unsigned long long before = __ballot(lane < k && (l < dn || (l == dn && lj < jn)));
+                const unsigned long long same = __ballot(lane < k && lj == jn);
+                const int pos = __builtin_popcountll(before);
+                const bool ok = pos < k && same == 0ull;              // (wave-uniform) pos == k: the row's bar moved while draining
+                if (ok && lane >= pos && lane < k - 1) { ldr[lane + 1] = l; ljr[lane + 1] = lj; }
+                if (ok && lane == pos) { ldr[lane] = dn; ljr[lane] = jn; }
+                if (ok) {
+                    const double nk = (pos >= k - 1) ? dn : pk2;     // the new k-th distance
+                    const double tau = nk < bound2 ? nk : bound2;
+                    const float ab = alpha - knn_bar_mfma(tau, pk.x, pk.y);
+                    if (lane == 0) qs[wave][Rn][6] = tau;
+                    if (bar_lane && row == Rn) { if (F < 4) a0 = ab; else a1 = ab; }
+                }
+            }
+        }
+    };
+    auto run_tile = [&](const float* cur, float* nxt, int t) {
+        if (t + 1 < ntiles) stage(t + 1, nxt);
+        fz_f4 nb0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
+        fz_f4 nb1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
+#pragma unroll 2
+        for (int s = 0; s < TILE / 64; ++s) {
+            const fz_f4 b0 = nb0, b1 = nb1;
+            if (s + 1 < TILE / 64) {
+                nb0 = *reinterpret_cast<const fz_f4*>(cur + (s + 1) * 512 + lane * 4);
+                nb1 = *reinterpret_cast<const fz_f4*>(cur + (s + 1) * 512 + 256 + lane * 4);
+            }
+            fz_f4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[g], fz_f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[g], acc[g], 0, 0, 0);
+            int sg = 0;                                              // OR of the 16 sign bits: any product under its row's bar
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sg |= __float_as_int(acc[g][r]);
+            if (__any(sg < 0)) {
+                unsigned pm = 0u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pm |= (__float_as_uint(acc[g][r]) >> 31) << (4 * g + r);
+                slow(pm, cur + s * 512, t * TILE + s * 64);
+            }
+        }
+        __syncthreads();
+    };
+    stage(0, tA);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+        run_tile(tA, tB, t);
+        if (t + 1 < ntiles) run_tile(tB, tA, t + 1);
+    }
+    for (int R = 0; R < 16; ++R) {
+        const int64_t i = i0 + R;
+        if (i < N && lane < k) idx[(i * K + tree) * k + lane] = (Ld[R * kpad + lane] < bound2) ? Lj[R * kpad + lane] : M;
+    }
+}
+
+}  // namespace fz
