@@ -217,3 +217,59 @@ def test_screened_search_is_the_exact_search(scale, monkeypatch):
             want = np.argsort(d2, kind='stable')[:k]
             got = out['screen'][i, t * k:(t + 1) * k]
             np.testing.assert_array_equal(np.sort(d2[got]), np.sort(d2[want]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['ties', 'bound', 'single_set', 'F3', 'F6', 'k40', 'unrelated_sets', 'ragged'])
+def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
+    """fz_knn_mfma.h (fp32 MFMA screen, seeds from feature set 0, (distance, index) ordered lists) returns the
+    neighbour table of the all-fp64 ascending scan (FZ_KNN_FP64=1) bit for bit: exact duplicates among the models
+    (ties resolved by model index, also at the k-th place and among the seeds), a finite distance bound, one
+    feature set (no seeds), other feature counts, k > 32, feature sets that are NOT realisations of the same
+    models (the seeds are then just k arbitrary distinct models), sizes that fill neither a tile nor a wave."""
+    from frankenz_amd.engine import get_engine
+    rs = np.random.RandomState(len(case) * 13 + 5)
+    K, M, F, N, k, bound = 4, 3000, 5, 203, 20, np.inf
+    if case == 'single_set': K = 1
+    if case == 'F3': F = 3
+    if case == 'F6': F = 6
+    if case == 'k40': k = 40
+    if case == 'ragged': M, N = 1000 + 37, 17
+    base = rs.normal(22.0, 1.0, size=(M, F))
+    noise = 0.05
+    if case == 'ties':
+        base[500:1500] = base[:1000]                                   # exact duplicates in every set
+        noise = 0.0                                                    # ... and identical sets: seeds == answer
+    feats = np.stack([base + rs.normal(0, noise, size=(M, F)) if noise else base for _ in range(K)])
+    if case == 'unrelated_sets':
+        feats = np.stack([rs.permutation(base) for _ in range(K)])
+    feats = feats.astype(np.float32)
+    q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
+    if case == 'ties':
+        q[:50] = feats[0][rs.choice(1000, 50)].astype(np.float64)        # distance exactly 0 to two models each
+    if case == 'bound':
+        bound = 0.25
+    eng = get_engine()
+    eng.upload_models(np.ones((M, F)), np.zeros((M, F)), np.ones((M, F)))
+    eng.knn_upload_trees(feats)
+    out = {}
+    for name in ('mfma', 'fp64'):
+        if name == 'fp64':
+            monkeypatch.setenv('FZ_KNN_FP64', '1')
+        idx = np.empty((N, K * k), dtype=np.int64)
+        eng.knn_query(np.ascontiguousarray(q), k, bound, idx)
+        out[name] = idx
+    monkeypatch.delenv('FZ_KNN_FP64')
+    np.testing.assert_array_equal(out['mfma'], out['fp64'])
+    # the host's own float64 brute force: stable argsort = ascending (distance, index)
+    for i in range(0, N, 29):
+        for t in range(K):
+            d2 = ((q[i][None, :] - feats[t].astype(np.float64)) ** 2).sum(axis=1)
+            want = np.argsort(d2, kind='stable')[:k]
+            want = np.where(d2[want] < bound ** 2, want, M)
+            got = out['mfma'][i, t * k:(t + 1) * k]
+            if case == 'ties':
+                np.testing.assert_array_equal(got, want)
+            else:
+                np.testing.assert_array_equal(np.sort(d2[got[got < M]]), np.sort(d2[want[want < M]]))
+                assert (got == M).sum() == (want == M).sum()
