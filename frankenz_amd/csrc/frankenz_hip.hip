@@ -153,6 +153,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     FZCHK(copy_out(c, &fl, c->d_flags.p, sizeof fl));
     if (fl & 2) return fail(-4, "models_mask must be binary (0/1)");
     c->M = M; c->Mp = Mp; c->B = B; c->BT = BT;
+    c->mc_rec0_valid = c->mc_rec1_valid = false;
     c->models_masked = (fl & 1) || (BT != B);
     c->models_wild = (fl & 4) != 0;
     // band-constant model errors (zeros for a template grid, a common floor, the SURVEY 8d
@@ -258,6 +259,54 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
         FZCHK(c->d_normtab.ensure(tab.size() * 8));
         FZCHK(copy_in(c, c->d_normtab.p, tab.data(), tab.size() * 8));
     }
+    // many dictionary widths: tables of the class-sorted stack (k_fused MC) -- the kernel's copy of the model records
+    // is ordered by class, so every object's candidate list comes out grouped by class and the PDF stage can keep ONE
+    // histogram, convolved with its class's kernel whenever the class changes.  Limits: half-widths <= 63 (the taps
+    // sit in two registers across the wave), G <= 768 (the result row sits in 12 registers per lane).
+    c->mc_ok = false; c->mc_rec0_valid = c->mc_rec1_valid = false;
+    if (!single) {
+        std::vector<int32_t> present((size_t)c->D, 0);
+        int64_t W0 = 0;
+        for (int64_t j = 0; j < M; ++j) { present[hs[j]] = 1; W0 = std::max<int64_t>(W0, c->h_widths[hs[j]]); }
+        const int64_t Gp = G + 2 * W0;
+        if (W0 <= 63 && G <= 768 && Gp < 1024) {
+            std::vector<int32_t> rank((size_t)c->D, -1), rwidth; std::vector<int64_t> roff, start;
+            for (int64_t d = 0; d < c->D; ++d) if (present[d]) { rank[d] = (int32_t)rwidth.size(); rwidth.push_back((int32_t)c->h_widths[d]); roff.push_back(c->h_offsets[d]); }
+            const size_t C = rwidth.size();
+            start.assign(C + 1, 0);
+            for (int64_t j = 0; j < M; ++j) ++start[rank[hs[j]] + 1];
+            for (size_t r = 0; r < C; ++r) start[r + 1] += start[r];
+            std::vector<int32_t> perm((size_t)M), tag((size_t)Mp, 0);
+            for (int64_t j = 0; j < M; ++j) {                    // stable: models keep their order inside a class
+                const int32_t r = rank[hs[j]];
+                const int64_t nj = start[r]++;
+                perm[nj] = (int32_t)j; tag[nj] = (r << 10) | (int32_t)(hy[j] + W0);
+            }
+            std::vector<double> ntab(C * (size_t)Gp, 1.0);
+            size_t r = 0;
+            for (int64_t d = 0; d < c->D; ++d) {
+                if (!present[d]) continue;
+                const int64_t w = c->h_widths[d], len = c->h_offsets[d + 1] - c->h_offsets[d];
+                const double* cdf = c->h_kcdf.data() + c->h_offsets[d];
+                for (int64_t q = 0; q < Gp; ++q) {
+                    const int64_t pp = q - W0;
+                    if (pp + w < 0 || pp - w > G - 1) continue;
+                    const int64_t lo = std::max<int64_t>(pp - w, 0), hi = std::min<int64_t>(pp + w + 1, G);
+                    const int64_t lpad = lo - (pp - w), hpad = hi - (pp + w + 1);
+                    double mass = cdf[len + hpad - 1];
+                    if (lpad != 0) mass -= cdf[lpad - 1];
+                    ntab[r * Gp + q] = mass;
+                }
+                ++r;
+            }
+            FZCHK(c->d_mc_tag.ensure(Mp * 4)); FZCHK(c->d_mc_perm.ensure(M * 4)); FZCHK(c->d_mc_width.ensure(C * 4));
+            FZCHK(c->d_mc_off.ensure(C * 8)); FZCHK(c->d_mc_norm.ensure(ntab.size() * 8));
+            FZCHK(copy_in(c, c->d_mc_tag.p, tag.data(), Mp * 4)); FZCHK(copy_in(c, c->d_mc_perm.p, perm.data(), M * 4));
+            FZCHK(copy_in(c, c->d_mc_width.p, rwidth.data(), C * 4)); FZCHK(copy_in(c, c->d_mc_off.p, roff.data(), C * 8));
+            FZCHK(copy_in(c, c->d_mc_norm.p, ntab.data(), ntab.size() * 8));
+            c->mc_ok = true; c->mc_gp = (int32_t)Gp; c->mc_w0 = (int32_t)W0;
+        }
+    }
     c->label_mode = 1; c->label_M = M;
     return 0;
 }
@@ -317,7 +366,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (fl & 1) return fail(-4, "gauss_kde labels: non-finite label or label error");
     if (fl & 2) return fail(-3, "gauss_kde labels: a label's window lies wholly below the grid "
                                 "(the reference's negative-index slicing there is not reproduced)");
-    c->G = G; c->label_mode = 2; c->label_M = M;
+    c->G = G; c->label_mode = 2; c->label_M = M; c->mc_ok = false;
     return 0;
 }
 

@@ -231,6 +231,11 @@ struct KdeView {
     const double* grid;
     int acc_stride;                       // doubles of LDS per object
     int lane_window;                      // DICT / GRID: windows up to this many grid points are added by their own lane
+    // class-sorted dictionary stack (k_fused<..., MC>): the kernel's model records are ordered by
+    // dictionary class; mc_tag[j'] = rank << 10 | (y_idx + mc_w0) of the model in place j'; per rank:
+    // half-width, kernel-table offset, and the edge-truncated mass per padded index [rank][mc_gp]
+    const int32_t* mc_tag; const int32_t* mc_width; const int64_t* mc_off; const double* mc_norm;
+    int32_t mc_gp, mc_w0;
 };
 // HIST: every label shares one dictionary kernel -> accumulate w/norm at the label's
 // grid index (one LDS atomic per selected model), convolve once at the end.
@@ -750,10 +755,133 @@ __device__ __forceinline__ void fused_tile_w(const SRC& src, const FastTabs& tb,
     }
 }
 
+// ---- PDF stage of the class-sorted dictionary stack (k_fused<..., MC>) ----------------------------
+// The model records this kernel walked are ordered by dictionary class, so the object's candidate list
+// is grouped by class.  One LDS histogram row (mc_gp = G + 2 W0 entries, W0 = the widest half-width
+// present): selected weights go in at their label index -- ONE ds_add_f64 per stacked model, as in the
+// single-kernel form -- and when the class of the entries changes the row is divided by the class's
+// edge-truncated kernel mass per index, convolved with the class's kernel into the lane's registers
+// (12 outputs per lane: G <= 768) and cleared.  pdf.py:599-620 adds each model's whole window instead
+// (~56 LDS adds per model at the benchmark's label errors); the sums agree to rounding order.
+// Weights, threshold rule, evidence and the hand-back of failed objects are those of the weight-space
+// stage in k_fused (candidates carry chi2; selection against the loop's estimate of the maximum,
+// entries within +-DEL of the threshold settled by a second walk with the exact evidence).
+template <class SRC, int U>
+__device__ __forceinline__ void pdf_stage_mc(const SRC& src, const KdeView& kv, const FastTabs& tb, double* row, const Cand* cb, int n,
+                                             const double* res, double wt_thresh, double lthr, int normalize, double* lmap,
+                                             double* levid, double* pdfs, int* redo, int64_t i, int lane) {
+    constexpr int NACC = 12;
+    constexpr double DEL = 1e-4;
+    const int G = (int)kv.G, Gp = kv.mc_gp, W0 = kv.mc_w0;
+    const double ref = uniform_d(res[0]), sn = uniform_d(res[1]), mxa = uniform_d(res[2]);
+    double out[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) out[a] = 0.0;
+    for (int k = lane; k < Gp; k += 64) row[k] = 0.0;
+    int ccur = -1;                                                // class rank whose weights sit in the row (wave-uniform)
+    // A lane owns NACC CONSECUTIVE outputs (t = NACC lane + a), so that the row values of its window are
+    // reused across its outputs: tap h needs row[base + a + h] for a = 0..NACC-1, a window that slides by one
+    // entry per tap -- ONE ds_read per lane and tap (the 12-slot window rotates through registers, the tap
+    // loop is unrolled by 12 so that the rotation is a renaming) instead of one per output and tap; with
+    // outputs strided across lanes the convolution of ~23 classes per object was bound by the CU's LDS pipe.
+    auto flush = [&]() {
+        const int wc = kv.mc_width[ccur], w2 = 2 * wc, sh = W0 - wc;
+        const double* nt = kv.mc_norm + (size_t)ccur * Gp;
+        const double* kr = kv.kern + kv.mc_off[ccur];
+        const double ka = (lane <= w2) ? kr[lane] : 0.0;          // w2 + 1 <= 127 taps in two registers across the wave
+        const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
+        for (int k = lane; k < Gp; k += 64) row[k] = row[k] / nt[k];
+        const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
+        const double* r0 = row + sh + NACC * min(lane, (G - 1) / NACC);      // lanes past G repeat the last lane's reads (unused sums); reads end < Gp + 12
+        double win[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) win[a] = r0[a];
+        for (int h = 0; h <= w2; h += NACC) {
+#pragma unroll
+            for (int u = 0; u < NACC; ++u) {
+                if (h + u <= w2) {                                // wave-uniform
+                    const int q = w2 - (h + u);
+                    const double tap = (q < 64) ? __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q))
+                                                : __hiloint2double(__builtin_amdgcn_readlane(kbh, q - 64), __builtin_amdgcn_readlane(kbl, q - 64));
+#pragma unroll
+                    for (int a = 0; a < NACC; ++a) out[a] = fma(win[(a + u) % NACC], tap, out[a]);
+                    win[u] = r0[NACC + h + u];                    // the entry that left the window makes room for the next one
+                }
+            }
+        }
+        for (int k = lane; k < Gp; k += 64) row[k] = 0.0;
+    };
+    // add the selected entries of one 64-entry block; entries are in class order, so the classes of a
+    // block are visited in lane order and each one is complete when the next begins
+    auto stack = [&](bool sel, int tag, double w) {
+        unsigned long long rem = __ballot(sel);
+        while (rem) {
+            const int r = __builtin_amdgcn_readlane(tag, __builtin_ctzll(rem)) >> 10;
+            if (r != ccur) { if (ccur >= 0) flush(); ccur = r; }
+            const bool mine = sel && (tag >> 10) == r;
+            if (mine) unsafeAtomicAdd(&row[tag & 1023], w);
+            rem &= ~__ballot(mine);
+        }
+    };
+    double lbest = -INFINITY, sc = 0.0;
+    bool anyamb = false;
+    for (int c0 = 0; c0 < n; c0 += 64 * U) {
+        Cand e[U]; bool in[U], sel[U]; double w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int k = c0 + u * 64 + lane; in[u] = k < n; e[u] = cb[in[u] ? k : 0]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double l = in[u] ? src.lnl_of_chi2(e[u].lnl) : -INFINITY;
+            lbest = fmax(lbest, l);
+            w[u] = exp_neg(l - ref, tb);
+            sc += in[u] ? w[u] : 0.0;
+            const double d = l - mxa;
+            sel[u] = in[u] && (d > lthr + DEL);
+            anyamb |= in[u] && !sel[u] && (d >= lthr - DEL);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) stack(sel[u], e[u].j, w[u]);
+    }
+    lbest = wave_max(lbest);
+    const double stot = sn + wave_sum(sc);
+    const double le = ref + log_pos(stot, tb);
+    if (__any(anyamb)) {                                          // wave-uniform, rare: a second pass over the classes
+        if (ccur >= 0) { flush(); ccur = -1; }
+        const double thr = wt_thresh * exp_neg(lbest - le, tb);   // wt_thresh * max(wt)
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int k = c0 + lane;
+            const bool in1 = k < n;
+            const Cand e1 = cb[in1 ? k : 0];
+            const double l = in1 ? src.lnl_of_chi2(e1.lnl) : -INFINITY;
+            const double d = l - mxa;
+            const bool amb = in1 && !(d > lthr + DEL) && (d >= lthr - DEL);
+            const bool s1 = amb && (exp_neg(l - le, tb) > thr);   // strict, pdf.py:591
+            stack(s1, e1.j, exp_neg(l - ref, tb));
+        }
+    }
+    if (ccur >= 0) flush();
+    const bool ok = (le - le == 0.0) && n > 0;
+    if (lane == 0) {
+        if (lmap) lmap[i] = lbest;
+        if (levid) levid[i] = le;
+        if (!ok) redo[1 + atomicAdd(redo, 1)] = (int)i;
+    }
+    double* o = pdfs + i * kv.G;
+    double tot = 0.0;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) if (NACC * lane + a < G) tot += out[a];
+    tot = wave_sum(tot);
+    const double f = normalize ? 1.0 / tot : exp_neg(ref - le, tb);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+        if (NACC * lane + a < G) o[NACC * lane + a] = !ok ? (double)NAN : (normalize ? out[a] / tot : out[a] * f);
+}
+
 // HO: instantiation for label sets with ONE dictionary kernel (histogram + one convolution: every
 // demo of the reference) -- the window-scatter code of the other KDE forms is not compiled in, so
 // that it cannot cost the hot kernel registers.
-template <class SRC, int TW, int NW, bool WM, bool HO>
+// MC (with WM and HO): many dictionary widths through class-sorted records -- see the PDF stage below.
+template <class SRC, int TW, int NW, bool WM, bool HO, bool MC = false>
 __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N_,
                                                     int M, double wt_thresh, int normalize,
                                                     Cand* __restrict__ cand, int64_t cap,
@@ -797,7 +925,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
     src.tb = stage_tabs(tabs, tid, NT);
     const FastTabs tb = src.tb;
     Cand* buf = cand + (size_t)gw * TW * cap;
-    const int32_t* posw = POSW ? kvp->pos : nullptr;
+    const int32_t* posw = POSW ? (MC ? kvp->mc_tag : kvp->pos) : nullptr;
     const double lt = (wt_thresh > 0.0) ? log(wt_thresh) - 1e-3 : -INFINITY;
     const float thrf = uniform_f((wt_thresh > 0.0) ? (float)(wt_thresh * 0.99) : 0.f);          // fp32 screen: a 1 % margin below the exact threshold
     const double lthr = (wt_thresh > 0.0) ? log(wt_thresh) : -INFINITY;
@@ -933,8 +1061,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
                 // A wave walks its object's list alone, so each trip is two dependent memory
                 // round trips (the entries, then the labels of the selected ones): U 64-entry
                 // blocks are kept in flight per trip to overlap them.
-                constexpr int U = HO ? 8 : 4;
-                if constexpr (WM) {
+                constexpr int U = (HO && !MC) ? 8 : 4;
+                if constexpr (MC) {
+                    pdf_stage_mc<SRC, U>(src, kv, tb, row, cb, n, res + o * FZ_RES, wt_thresh, lthr, normalize, lmap, levid, pdfs, redo, i, lane);
+                } else if constexpr (WM) {
                     // Candidates carry their fp64 chi2.  One walk: exact ln-like, exact maximum, the
                     // candidates' exact share of the evidence, and the stack -- weights relative to the
                     // loop's reference (an upper bound of every ln-like), selection against the loop's

@@ -108,16 +108,54 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     return 0;
 }
 
+// class-sorted copy of the model records (many dictionary widths, k_fused MC): row j' <- row perm[j'], pads in place
+static __global__ void k_permute_records(const double* __restrict__ in, const int* __restrict__ perm, int64_t M, int64_t Mp, int rw,
+                                         double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Mp * rw) return;
+    const int64_t j = e / rw; const int r = (int)(e - j * rw);
+    out[e] = in[(j < M ? (int64_t)perm[j] : j) * rw + r];
+}
+inline int fz_mc_records(fz_ctx* c, bool rec0) {
+    bool& valid = rec0 ? c->mc_rec0_valid : c->mc_rec1_valid;
+    if (valid) return 0;
+    const int rw = rec0 ? fz_rec_width(2 * c->BT) : fz_rec_width(c->BT);
+    DevBuf& dst = rec0 ? c->d_rec0p : c->d_rec1p;
+    FZCHK(dst.ensure((size_t)c->Mp * rw * 8));
+    const int64_t tot = c->Mp * rw;
+    hipLaunchKernelGGL(k_permute_records, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                       (rec0 ? c->d_rec0 : c->d_rec1).as<double>(), c->d_mc_perm.as<int>(), c->M, c->Mp, rw, dst.as<double>());
+    HIPCHK(hipGetLastError());
+    valid = true;
+    return 0;
+}
+
 // single-pass kernel; returns +1 (not an error) when its candidate workspace does
 // not fit the budget and the caller should take the two-pass route
 template <class SRC, int TW, int NW, bool WM>
-int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+int fz_launch_fused_wm(fz_ctx* c, const SRC& src_in, const fz::KdeView& kv_in, int64_t n, int64_t M, const fz_kde_opts* ko,
                        double* lmap, double* levid, double* pdfs) {
+    SRC src = src_in;
+    fz::KdeView kv = kv_in;
+    // many dictionary widths on the weight-space body: class-sorted records, one histogram, one convolution per class
+    // present (fz_kernels.h, pdf_stage_mc); FZ_NO_MC=1 keeps the per-model window adds
+    bool mc = false;
+    if constexpr (WM && (NW == 12 || NW == 4)) {      // (2,16) spills inside the model loop with this PDF stage: the dispatcher sends it to (2,12)
+        if (kv.kmode == fz::KDE_DICT && c->mc_ok && !getenv("FZ_NO_MC")) {
+            FZCHK(fz_mc_records(c, SRC::LMODE == 0));
+            src.mv.rec0 = c->d_rec0p.as<double>(); src.mv.rec1 = c->d_rec1p.as<double>();
+            kv.mc_tag = c->d_mc_tag.as<int32_t>(); kv.mc_width = c->d_mc_width.as<int32_t>(); kv.mc_off = c->d_mc_off.as<int64_t>();
+            kv.mc_norm = c->d_mc_norm.as<double>(); kv.mc_gp = c->mc_gp; kv.mc_w0 = c->mc_w0;
+            kv.acc_stride = c->mc_gp + 16;            // + the tail pad the sliding window of the convolution reads into
+            mc = true;
+        }
+    }
     // the PDF rows live inside the (static) tile buffers when half of the waves' rows fit in one, else in dynamic LDS
     const size_t TDB = (size_t)SRC::template tile_doubles<SRC::template tile_len<NW>()>() +
-                       ((WM && kv.kmode == fz::KDE_HIST) ? SRC::template tile_len<NW>() / 2 : 0);       // + the index words (k_fused, POSW)
+                       ((WM && (kv.kmode == fz::KDE_HIST || mc)) ? SRC::template tile_len<NW>() / 2 : 0);       // + the index words (k_fused, POSW)
     const size_t lds = ((size_t)((NW + 1) / 2) * kv.acc_stride <= TDB) ? 0 : (size_t)NW * kv.acc_stride * 8;
     auto kern = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, TW, NW, WM, true> : fz::k_fused<SRC, TW, NW, WM, false>;
+    if constexpr (WM && (NW == 12 || NW == 4)) { if (mc) kern = fz::k_fused<SRC, TW, NW, WM, true, true>; }
     {
         hipFuncAttributes fa;
         HIPCHK(hipFuncGetAttributes(&fa, (const void*)kern));
@@ -140,8 +178,10 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
         else return 1;                                             // cannot fill even half the chip
     } else if (fit < need) return 1;
     if (c->d_cand.ensure((size_t)blocks * NW * per_wave) != 0) return 1;      // no room for the lists: two-pass route
-    FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
+    // slot 0: the view of the main launch; slot 1: the caller's view (the sweep below always runs the general kernels)
+    FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_kv.as<fz::KdeView>() + 1, &kv_in, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
     // objects the weight-space body hands back (no candidate / no fp32 weight at all): counter + list
     if (WM) {
         FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
@@ -157,9 +197,9 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
             // sweep: the fp64 ln-space body over exactly the handed-back objects (their chunk-level
             // indices are the object map; the count stays on the device, so nothing waits for it)
             constexpr int SW = 4;
-            auto sweep = (kv.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, 1, SW, false, true> : fz::k_fused<SRC, 1, SW, false, false>;
+            auto sweep = (kv_in.kmode == fz::KDE_HIST) ? fz::k_fused<SRC, 1, SW, false, true> : fz::k_fused<SRC, 1, SW, false, false>;
             constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
-            size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+            size_t lds2 = ((size_t)((SW + 1) / 2) * kv_in.acc_stride <= TDB2) ? 0 : (size_t)SW * kv_in.acc_stride * 8;
             {
                 hipFuncAttributes fa;
                 HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
@@ -168,8 +208,8 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
             const int64_t sblocks = std::min<int64_t>(std::min<int64_t>(c->cu_count, (n + SW - 1) / SW), (int64_t)((size_t)blocks * NW * per_wave / ((size_t)SW * M * sizeof(fz::Cand))));
             if (lds2 <= 160 * 1024 && sblocks >= 1) {
                 HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                hipLaunchKernelGGL(sweep, dim3((unsigned)sblocks), dim3(SW * 64), lds2, c->stream, src, c->d_kv.as<fz::KdeView>(),
-                                   kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
+                hipLaunchKernelGGL(sweep, dim3((unsigned)sblocks), dim3(SW * 64), lds2, c->stream, src_in, c->d_kv.as<fz::KdeView>() + 1,
+                                   kv_in.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs,
                                    c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
             }
         }
@@ -273,6 +313,8 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             // weight-space body with wide records (general mode A: y and ye^2; 7 and 8 bands): 16 waves leave
             // 128 VGPRs, and the body then spills inside the model loop (3-4x slower); 12 waves (168 VGPRs) do not
             if (tw == 2 && nw == 16 && fz_use_wspace(src) && (SRC::LMODE == 0 || SRC::NB >= 7)) nw = 12;
+            // ... and so does the class-sorted stack of many dictionary widths (its PDF stage keeps a 12-register result row)
+            if (tw == 2 && nw == 16 && fz_use_wspace(src) && kv.kmode == fz::KDE_DICT && c->mc_ok && !getenv("FZ_NO_MC")) nw = 12;
             else if (tw == 4 && SRC::PREF_2x8) { tw = 2; nw = 8; }
             if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);

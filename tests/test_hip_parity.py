@@ -740,3 +740,32 @@ def test_grid_kde_labels_above_the_grid_contribute_nothing():
         close(hp.gauss_kde(y, ys, grid, y_wt=wt, **kw), fo.gauss_kde(y, ys, grid, y_wt=wt, **kw), atol=1e-14)
     with pytest.raises(IndexError):
         hp.gauss_kde(np.array([-3.0, 1.0]), np.array([0.05, 0.05]), grid)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
+@pytest.mark.parametrize('N', [300, 20000])                        # one object per wave (1, 4) / the 12-wave geometry
+def test_class_sorted_stack_of_many_kernel_widths(kw, N, monkeypatch):
+    """gauss_kde_dict with many kernel widths on the weight-space body: model records ordered by dictionary class,
+    one histogram per class present and one convolution per class (pdf_stage_mc) -- same PDFs as the per-model
+    window adds (FZ_NO_MC=1) and as the oracle; labels at both grid edges (truncated kernel masses), classes with a
+    single model, a class boundary inside a 64-entry block."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(616 + N % 7)
+    M, B = 2500, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.5 * rs.randn(N, B); Xe = np.full((N, B), 0.5); Xm = np.ones((N, B))
+    z = np.clip(rs.uniform(-0.3, 7.3, M), 0.0, 7.0)                 # piles at both edges of the grid
+    ze = rs.uniform(0.01, 0.12, M)                                 # ~28 classes, half-widths 5..60
+    ze[7] = 0.125; ze[8] = 0.006                                   # classes of one model (widest: 63; narrowest)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    p0, (lm0, le0) = run()
+    monkeypatch.setenv('FZ_NO_MC', '1')
+    p1, (lm1, le1) = run()
+    monkeypatch.delenv('FZ_NO_MC')
+    assert np.isfinite(p0).all()
+    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-14, atol=0); close(le0, le1, **EVID)
+    np.testing.assert_allclose(p0.sum(axis=1), 1.0, rtol=1e-12)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:25].copy(), Xe[:25].copy(), Xm[:25].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(p0[:25], rp, rtol=1e-8, atol=1e-14); close(lm0[:25], rlm); close(le0[:25], rle, **EVID)
