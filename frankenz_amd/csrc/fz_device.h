@@ -205,14 +205,15 @@ struct Phot {
             slogv = o.slv;
         } else {
             // inter = sum m (y x)/var ; shape = sum m (y y)/var ; s = inter/shape.
-            // Both use the SAME 1/var factor, so a model identical to the data gives
+            // Both use the SAME y/var factor, so a model identical to the data gives
             // inter == shape bit for bit and s == 1 exactly, as in the reference.
             double inter = 0.0, shape = 0.0;
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
                 const double w = MASKED ? o.v[b] * tm[b] : o.v[b];
-                inter = fma(m.y[b] * o.x[b], w, inter);
-                shape = fma(m.y[b] * m.y[b], w, shape);
+                const double yw = m.y[b] * w;            // shared factor: three instructions per band, and x == y still gives inter == shape
+                inter = fma(yw, o.x[b], inter);
+                shape = fma(yw, m.y[b], shape);
             }
             double s;
             if (SAFE || !(shape > 1e-280 && shape < 1e280)) {
@@ -225,8 +226,8 @@ struct Phot {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
                 const double d = fma(-s, m.y[b], o.x[b]);
-                const double q = (d * d) * o.v[b];
-                chi2 = MASKED ? fma(q, tm[b], chi2) : chi2 + q;
+                if (MASKED) chi2 = fma((d * d) * o.v[b], tm[b], chi2);
+                else chi2 = fma(d * o.v[b], d, chi2);    // three instructions per band; d == 0 (self match) still gives exactly 0
             }
             r.scale = s; r.shape = shape;
             slogv = o.slv;
