@@ -26,4 +26,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_headline -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_summarize -- python3 bench.py --workload summarize --nobj 1000000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_summarize.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_planes -- python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_planes.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_predict -- python3 bench.py --workload predict --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_predict.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_knn -- python3 bench.py --workload knn --nobj 100000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_knn.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_many_widths -- python3 bench.py --label-err varying --nobj 262144 --no-cpu --steps 2 --warmup 1 > $O/m_stats_many_widths.log 2>&1
 tail -c 600 $O/m_bench_fit_predict_modeA.json
