@@ -104,8 +104,9 @@ __device__ __forceinline__ float knn_bar_mfma(double tau, float uq2, float e) {
 //    at their largest instead of +inf -- the k ln(M / k) admissions of a cold scan (half of them in
 //    the first 1 % of the models) shrink to the few models that really sit inside that ball.
 // FX: the feature count when it is a compile-time constant (5: the usual five bands), 0 = runtime F.
-template <int TILE, int FX>
-static __global__ __launch_bounds__(256) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
+// NWB: waves per block (they share the LDS tiles and meet at one barrier per tile; the default launch is ONE wave per block).
+template <int TILE, int FX, int NWB>
+static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
                                                          const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed) {
@@ -113,16 +114,16 @@ static __global__ __launch_bounds__(256) void k_knn_mfma(const float* __restrict
     constexpr int FL = FX ? FX : 6;                    // feature loop bound of the exact re-check
     __shared__ __attribute__((aligned(16))) float tA[TF];
     __shared__ __attribute__((aligned(16))) float tB[TF];
-    __shared__ double qs[4][16][8];                   // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
+    __shared__ double qs[NWB][16][8];                   // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
     extern __shared__ double s_lists[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tree = blockIdx.y + tree0;
-    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    const int64_t i0 = ((int64_t)blockIdx.x * NWB + wave) * 16;
     const float* bm = bmat + (size_t)tree * (Mp >> 6) * 512;
     const int row = lane & 15, sl = lane >> 4;
     double* Ld = s_lists + (size_t)wave * 16 * kpad;                                     // [16][kpad]
-    int* Lj = reinterpret_cast<int*>(s_lists + (size_t)4 * 16 * kpad) + (size_t)wave * 16 * kpad;
+    int* Lj = reinterpret_cast<int*>(s_lists + (size_t)NWB * 16 * kpad) + (size_t)wave * 16 * kpad;
     for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
     // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
     {
@@ -188,9 +189,9 @@ static __global__ __launch_bounds__(256) void k_knn_mfma(const float* __restrict
     auto stage = [&](int tile, float* dst) {             // contiguous: 1-KB wave-instructions
         const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
 #pragma unroll
-        for (int c = 0; c < TF * 4 / (256 * 16); ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 4096 + (uint32_t)tid * 16u),
-                                             (__attribute__((address_space(3))) void*)(dst + c * 1024 + wave * 256), 16, 0, 0);
+        for (int c = 0; c < TF * 4 / (NWB * 64 * 16); ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * (NWB * 1024) + (uint32_t)tid * 16u),
+                                             (__attribute__((address_space(3))) void*)(dst + c * (NWB * 256) + wave * 256), 16, 0, 0);
     };
     // admission path.  pm: this lane's 16-bit mask of (g, r) products under the bar.
     auto slow = [&](unsigned pm, const float* blk, int jb) {
