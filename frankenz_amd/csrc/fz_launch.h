@@ -3,6 +3,7 @@
 #include "fz_ctx.h"
 #include "fz_kernels.h"
 #include "fz_ol.h"
+#include "fz_nolist.h"
 
 inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
     using namespace fz;
@@ -242,6 +243,77 @@ int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
 }
 
+// share of the launch's (object, model) pairs within the weight threshold, from a sample (fz_nolist.h); < 0: not applicable
+template <class SRC>
+double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko) {
+    if constexpr (!fz_has_wspace<SRC>()) return -1.0;
+    else {
+        if (!fz_use_wspace(src) || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return -1.0;
+        const int S = 256;
+        if (c->d_flags.ensure(64) != 0) return -1.0;
+        if (hipMemsetAsync(c->d_flags.p, 0, 8, c->stream) != hipSuccess) return -1.0;
+        hipLaunchKernelGGL((fz::k_nl_probe<SRC>), dim3(S / 4), dim3(256), 0, c->stream, src, n, (int)M, S, ko->wt_thresh, c->omap,
+                           c->d_flags.as<unsigned long long>());
+        unsigned long long cnt = 0;
+        if (hipMemcpyAsync(&cnt, c->d_flags.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1.0;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
+        return (double)cnt / ((double)S * (double)((M + 255) / 256) * 64.0);
+    }
+}
+
+// list-free two-pass form for broad likelihoods (fz_nolist.h); +1 = not applicable / does not fit
+template <class SRC>
+int fz_launch_nolist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                     double* lmap, double* levid, double* pdfs) {
+    if constexpr (!fz_has_wspace<SRC>()) return 1;
+    else {
+        constexpr int NW = 16, SW = 4;
+        if (!fz_use_wspace(src) || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return 1;
+        auto k1 = fz::k_nl_max<SRC, NW>;
+        auto k2 = fz::k_nl_main<SRC, NW>;
+        const size_t lds = (size_t)NW * kv.acc_stride * 8;
+        {
+            hipFuncAttributes fa;
+            HIPCHK(hipFuncGetAttributes(&fa, (const void*)k2));
+            if (fa.sharedSizeBytes + lds > 160 * 1024) return 1;
+        }
+        HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FZCHK(c->d_nlmax.ensure((size_t)n * 8));
+        FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
+        HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+        FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
+        HIPCHK(hipMemsetAsync(c->d_redo.p, 0, sizeof(int), c->stream));
+        // the sweep over handed-back objects keeps candidate lists: SW waves' worth
+        const size_t sweep_ws = (size_t)c->cu_count * SW * M * sizeof(fz::Cand);
+        if ((int64_t)sweep_ws > c->ws_limit || c->d_cand.ensure(sweep_ws) != 0) return 1;
+        HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
+        int b1 = 1, b2 = 1;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (const void*)k1, NW * 64, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (const void*)k2, NW * 64, lds));
+        const int64_t g1 = std::min<int64_t>(((n + 1) / 2 + NW - 1) / NW, (int64_t)std::max(1, b1) * c->cu_count);
+        const int64_t g2 = std::min<int64_t>((n + NW - 1) / NW, (int64_t)std::max(1, b2) * c->cu_count);
+        Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+        hipLaunchKernelGGL(k1, dim3((unsigned)g1), dim3(NW * 64), 0, c->stream, src, n, (int)M, c->omap, c->d_nlmax.as<double>());
+        hipLaunchKernelGGL(k2, dim3((unsigned)g2), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
+                           (int)M, ko->wt_thresh, ko->normalize, c->omap, c->d_nlmax.as<double>(), lmap, levid, pdfs, c->d_redo.as<int>());
+        {
+            auto sweep = fz::k_fused<SRC, 1, SW, false, true>;
+            constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
+            const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+            hipFuncAttributes fa;
+            HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
+            if (fa.sharedSizeBytes + lds2 <= 160 * 1024) {
+                HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>(c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, src,
+                                   c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
+                                   lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+}
+
 // object-per-lane single pass (fz_ol.h); +1 = does not fit, caller takes the k_fused route
 template <class SRC, int OPL>
 int fz_launch_ol(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
@@ -289,6 +361,18 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int r = 1;
+        // broad likelihoods run without candidate lists (fz_nolist.h: two passes over the models, nothing in HBM).  The
+        // share of pairs within the weight threshold is measured on 256 sampled objects of the launch; FZ_NOLIST=1 / 0
+        // forces / forbids the form (launches below 16 384 objects keep the lists unless forced)
+        {
+            const char* e = getenv("FZ_NOLIST");
+            int want = e ? atoi(e) : -1;
+            if (want < 0 && n >= 16384) want = fz_nolist_probe<SRC>(c, src, kv, n, M, ko) > 0.27 ? 1 : 0;
+            if (want == 1) {
+                r = fz_launch_nolist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                if (r <= 0) return r;
+            }
+        }
         if constexpr (SRC::WPOW == 3 && SRC::NB == 5) {
             if (fz_use_wspace(src) && getenv("FZ_OL") && !c->omap) {
                 r = fz_launch_ol<SRC, 2>(c, src, kv, n, M, ko, lmap, levid, pdfs);

@@ -769,3 +769,34 @@ def test_class_sorted_stack_of_many_kernel_widths(kw, N, monkeypatch):
     np.testing.assert_allclose(p0.sum(axis=1), 1.0, rtol=1e-12)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:25].copy(), Xe[:25].copy(), Xm[:25].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p0[:25], rp, rtol=1e-8, atol=1e-14); close(lm0[:25], rlm); close(le0[:25], rle, **EVID)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
+@pytest.mark.parametrize('force', [None, '1'])
+def test_list_free_form_for_broad_likelihoods(kw, force, monkeypatch):
+    """faint objects (most models within wt_thresh of the best): the launcher measures the share of pairs within the
+    threshold on a sample and runs the list-free two-pass form (fz_nolist.h) -- same PDFs / lmap / evidence as the
+    candidate-list form (FZ_NOLIST=0) and as the oracle; forced (FZ_NOLIST=1) on bright objects too, where a handful
+    of models carry the whole posterior, a training-set self match (chi2 == 0) sits among the models and one object
+    matches nothing (every chi2 far above the mode)."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(717)
+    M, N, B = 1500, 17000, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = Y * rs.uniform(0.02, 0.08, size=(M, B)); Ym = np.ones((M, B))
+    noise = 6.0 * SDSS5 if force is None else 0.3 * SDSS5
+    X = Y[rs.choice(M, N)] + noise * rs.randn(N, B); Xe = np.tile(noise, (N, 1)); Xm = np.ones((N, B))
+    X[5] = Y[11]                                                   # exact self match
+    X[6] = 1e4                                                     # matches nothing
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    if force:
+        monkeypatch.setenv('FZ_NOLIST', force)
+    p1, (lm1, le1) = run()
+    monkeypatch.setenv('FZ_NOLIST', '0')
+    p0, (lm0, le0) = run()
+    monkeypatch.delenv('FZ_NOLIST')
+    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[:25].copy(), Xe[:25].copy(), Xm[:25].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    close(p1[:25], rp, rtol=1e-8, atol=1e-14); close(lm1[:25], rlm); close(le1[:25], rle, **EVID)
