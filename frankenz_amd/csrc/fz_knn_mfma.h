@@ -30,8 +30,9 @@ namespace fz {
 
 typedef float fz_f4 __attribute__((ext_vector_type(4)));
 
-#define FZ_KM_TILE 128                  // models per LDS tile
+#define FZ_KM_TILE 64                   // models per LDS tile
 #define FZ_KM_TFLOATS (FZ_KM_TILE * 8)  // 8 slots per model
+#define FZ_KM_TSTR 528                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi)
 
 // per-feature mean of one feature set (one block per set), in fp64
 static __global__ __launch_bounds__(256) void k_knn_center(const float* __restrict__ in, int64_t M, int F, float* __restrict__ cen) {
@@ -77,10 +78,31 @@ static __global__ __launch_bounds__(256) void k_knn_pack_mfma(const float* __res
         slot[F] = 1.f; slot[F + 1] = 1e30f;
     }
     const int64_t blk = j >> 6; const int m = (int)(j & 63), g = m >> 4, col = m & 15;
-    float* o = bmat + ((size_t)t * (Mp >> 6) + blk) * 512;
+    float* o = bmat + ((size_t)t * (Mp >> 6) + blk) * FZ_KM_TSTR;
     for (int s = 0; s < 8; ++s) o[(s >> 2) * 256 + ((s & 3) * 16 + col) * 4 + g] = slot[s];
 }
 
+
+// bounding box of every 64-model tile (behind the tile's operands): the search skips a tile when the box is farther from
+// each of the wave's 16 queries than that query's admission bar.  Stored slightly enlarged (one float rounding), so that
+// the fp32 lower bound formed from it stays below the exact distance.  enable = 0: boxes that never exclude anything.
+static __global__ __launch_bounds__(64) void k_knn_boxes(const float* __restrict__ in, int64_t M, int F, int64_t Mp,
+                                                         const int* __restrict__ perm, float* __restrict__ bmat, int enable) {
+    const int lane = threadIdx.x, t = blockIdx.y;
+    const int64_t blk = blockIdx.x, j = blk * 64 + lane;
+    float* o = bmat + ((size_t)t * (Mp >> 6) + blk) * FZ_KM_TSTR + 512;
+    const int64_t oj = (j < M) ? (perm ? (int64_t)perm[(size_t)t * M + j] : j) : 0;
+    for (int f = 0; f < 8; ++f) {
+        float lo = INFINITY, hi = -INFINITY;
+        if (f < F && j < M) { const float v = in[((size_t)t * M + oj) * F + f]; if (v == v) { lo = v; hi = v; } }
+        for (int d = 32; d > 0; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+        if (lane == 0) {
+            const bool on = enable && f < F;
+            o[f] = on ? lo - 1.2e-7f * fabsf(lo) : -INFINITY;
+            o[8 + f] = on ? hi + 1.2e-7f * fabsf(hi) : INFINITY;
+        }
+    }
+}
 
 // 12-bit Morton prefix of a feature vector: features quantised to 10 bits inside the set's bounding box (lo, scale),
 // bits interleaved most significant first.  Used to order a set's models (host, at upload), to order the queries
@@ -155,7 +177,8 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
                                                          const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd) {
-    constexpr int TF = TILE * 8;
+    static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
+    constexpr int TF = FZ_KM_TSTR;
     constexpr int FL = FX ? FX : 6;                    // feature loop bound of the exact re-check
     __shared__ __attribute__((aligned(16))) float tA[TF];
     __shared__ __attribute__((aligned(16))) float tB[TF];
@@ -165,7 +188,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tree = blockIdx.y + tree0;
     const int64_t i0 = ((int64_t)blockIdx.x * NWB + wave) * 16;
-    const float* bm = bmat + (size_t)tree * (Mp >> 6) * 512;
+    const float* bm = bmat + (size_t)tree * (Mp >> 6) * FZ_KM_TSTR;
     const int row = lane & 15, sl = lane >> 4;
     double* Ld = s_lists + (size_t)wave * 16 * kpad;                                     // [16][kpad]
     int* Lj = reinterpret_cast<int*>(s_lists + (size_t)NWB * 16 * kpad) + (size_t)wave * 16 * kpad;
@@ -229,6 +252,15 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         a0 = aslot(sl, ab); a1 = aslot(4 + sl, ab);
     }
     const bool bar_lane = sl == (F & 3);
+    // for the tile test: this lane's row in fp32 (+ the rounding that cost), and the row's bar in distance units
+    float qf[FL], eq[FL];
+#pragma unroll
+    for (int f = 0; f < FL; ++f) { qf[f] = (float)qs[wave][row][f]; eq[f] = 1.3e-7f * fabsf(qf[f]); }
+    float barrow;
+    {
+        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
+        barrow = knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
+    }
 
     const int ntiles = (M + TILE - 1) / TILE;
     // Visiting order.  The set's models are stored in Morton order (upload) and the wave's queries are neighbours
@@ -252,12 +284,13 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         right = !right;
         return t;
     };
-    auto stage = [&](int tile, float* dst) {             // contiguous: 1-KB wave-instructions
+    auto stage = [&](int tile, float* dst) {             // 2112 contiguous bytes: 132 16-byte chunks over the wave's 64 lanes
         const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
 #pragma unroll
-        for (int c = 0; c < TF * 4 / (NWB * 64 * 16); ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * (NWB * 1024) + (uint32_t)tid * 16u),
-                                             (__attribute__((address_space(3))) void*)(dst + c * (NWB * 256) + wave * 256), 16, 0, 0);
+        for (int c = 0; c < 3; ++c)
+            if (c < 2 || tid < 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + (uint32_t)tid * 16u),
+                                                 (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
     };
     // admission path.  pm: this lane's 16-bit mask of (g, r) products under the bar.
     auto slow = [&](unsigned pm, const float* blk, int jb) {
@@ -299,7 +332,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                 if (ok) {
                     const double nk = (pos >= k - 1) ? dn : pk2;     // the new k-th distance
                     const double tau = nk < bound2 ? nk : bound2;
-                    const float ab = alpha - knn_bar_mfma(tau, pk.x, pk.y);
+                    const float nbar = knn_bar_mfma(tau, pk.x, pk.y);
+                    const float ab = alpha - nbar;
+                    if (row == Rn) barrow = nbar;
                     if (lane == 0) qs[wave][Rn][6] = tau;
                     if (bar_lane && row == Rn) { if (F < 4) a0 = ab; else a1 = ab; }
                 }
@@ -310,6 +345,23 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     auto run_tile = [&](const float* cur, float* nxt, int n) {
         if (n + 1 < ntiles) { nxt_t = next_tile(); stage(nxt_t, nxt); }
         const int t = cur_t;
+        // lower bound of the distance from this lane's query to the tile's bounding box; the tile is skipped when it
+        // exceeds the bar of every row of the wave (then no model in it can be admitted: bar > tau >= the k-th distance)
+        bool reach;
+        {
+            const fz_f4 l0 = *reinterpret_cast<const fz_f4*>(cur + 512), l1 = *reinterpret_cast<const fz_f4*>(cur + 516);
+            const fz_f4 h0 = *reinterpret_cast<const fz_f4*>(cur + 520), h1 = *reinterpret_cast<const fz_f4*>(cur + 524);
+            float lb = 0.f;
+#pragma unroll
+            for (int f = 0; f < FL; ++f) {
+                const float lo = f < 4 ? l0[f & 3] : l1[f & 3], hi = f < 4 ? h0[f & 3] : h1[f & 3];
+                float m = fmaxf(fmaxf(lo - qf[f], qf[f] - hi), 0.f);
+                m = fmaxf(m - eq[f], 0.f);
+                lb = fmaf(m, m, lb);
+            }
+            reach = lb * 0.999999f <= barrow;
+        }
+        if (__any(reach)) {
         fz_f4 nb0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
         fz_f4 nb1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
 #pragma unroll 2
@@ -337,6 +389,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                     for (int r = 0; r < 4; ++r) pm |= (__float_as_uint(acc[g][r]) >> 31) << (4 * g + r);
                 slow(pm, cur + s * 512, t * TILE + s * 64);
             }
+        }
         }
         cur_t = nxt_t;
         __syncthreads();
