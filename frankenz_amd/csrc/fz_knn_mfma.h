@@ -32,7 +32,8 @@ typedef float fz_f4 __attribute__((ext_vector_type(4)));
 
 #define FZ_KM_TILE 64                   // models per LDS tile
 #define FZ_KM_TFLOATS (FZ_KM_TILE * 8)  // 8 slots per model
-#define FZ_KM_TSTR 528                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi)
+#define FZ_KM_TSTR 544                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi) + the box of its group of tiles
+#define FZ_KM_GT 8                      // tiles per group (aligned): a group whose box is out of reach is skipped at its first tile, unstaged
 
 // per-feature mean of one feature set (one block per set), in fp64
 static __global__ __launch_bounds__(256) void k_knn_center(const float* __restrict__ in, int64_t M, int F, float* __restrict__ cen) {
@@ -102,6 +103,22 @@ static __global__ __launch_bounds__(64) void k_knn_boxes(const float* __restrict
             o[8 + f] = on ? hi + 1.2e-7f * fabsf(hi) : INFINITY;
         }
     }
+}
+
+// box of every aligned group of FZ_KM_GT tiles, copied behind each of its tiles' own box (so that whichever tile a scan
+// enters the group through carries it)
+static __global__ __launch_bounds__(64) void k_knn_gboxes(int64_t Mp, float* __restrict__ bmat) {
+    const int lane = threadIdx.x, t = blockIdx.y;
+    const int64_t ntl = Mp >> 6, g0 = (int64_t)blockIdx.x * FZ_KM_GT;
+    float* base = bmat + (size_t)t * ntl * FZ_KM_TSTR;
+    if (lane >= 16) return;
+    float v = lane < 8 ? INFINITY : -INFINITY;
+    for (int u = 0; u < FZ_KM_GT; ++u) {
+        if (g0 + u >= ntl) break;
+        const float b = base[(g0 + u) * FZ_KM_TSTR + 512 + lane];
+        v = lane < 8 ? fminf(v, b) : fmaxf(v, b);
+    }
+    for (int u = 0; u < FZ_KM_GT; ++u) if (g0 + u < ntl) base[(g0 + u) * FZ_KM_TSTR + 528 + lane] = v;
 }
 
 // 12-bit Morton prefix of a feature vector: features quantised to 10 bits inside the set's bounding box (lo, scale),
@@ -269,14 +286,15 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     // the rest of the scan admits little (benchmark data: 55-65 admissions per query instead of 87).  The lists are
     // ordered by (distance, original index), so the result does not depend on the order.  One wave per block only:
     // waves sharing tiles would need a common start.
-    int nl = -1, nr = 0;                                  // next tile on the left / right of the start
+    int nl = -1, nr = 0, home = 0;                        // next tile on the left / right of the start
     if (NWB == 1 && ktab) {
         double qm[8];
 #pragma unroll
         for (int f = 0; f < 6; ++f) qm[f] = qs[wave][8][f];
-        const int home = ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
-        nr = __builtin_amdgcn_readfirstlane(home < ntiles ? home : ntiles - 1); nl = nr - 1;
+        const int hm = ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
+        nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); nl = nr - 1;
     }
+    home = nr;
     bool right = true;
     auto next_tile = [&]() -> int {
         int t;
@@ -284,11 +302,11 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         right = !right;
         return t;
     };
-    auto stage = [&](int tile, float* dst) {             // 2112 contiguous bytes: 132 16-byte chunks over the wave's 64 lanes
+    auto stage = [&](int tile, float* dst) {             // 2176 contiguous bytes: 136 16-byte chunks over the wave's 64 lanes
         const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (c < 2 || tid < 4)
+            if (c < 2 || tid < 8)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + (uint32_t)tid * 16u),
                                                  (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
     };
@@ -342,15 +360,15 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         }
     };
     int cur_t = next_tile(), nxt_t = 0;
-    auto run_tile = [&](const float* cur, float* nxt, int n) {
-        if (n + 1 < ntiles) { nxt_t = next_tile(); stage(nxt_t, nxt); }
+    auto run_tile = [&](const float* cur, float* nxt) -> bool {
+        const bool more = nr < ntiles || nl >= 0;         // tiles left on either side (before this tile's group test)
+        if (more) { nxt_t = next_tile(); stage(nxt_t, nxt); }
         const int t = cur_t;
         // lower bound of the distance from this lane's query to the tile's bounding box; the tile is skipped when it
         // exceeds the bar of every row of the wave (then no model in it can be admitted: bar > tau >= the k-th distance)
-        bool reach;
-        {
-            const fz_f4 l0 = *reinterpret_cast<const fz_f4*>(cur + 512), l1 = *reinterpret_cast<const fz_f4*>(cur + 516);
-            const fz_f4 h0 = *reinterpret_cast<const fz_f4*>(cur + 520), h1 = *reinterpret_cast<const fz_f4*>(cur + 524);
+        auto box_reach = [&](const float* bx) -> bool {
+            const fz_f4 l0 = *reinterpret_cast<const fz_f4*>(bx), l1 = *reinterpret_cast<const fz_f4*>(bx + 4);
+            const fz_f4 h0 = *reinterpret_cast<const fz_f4*>(bx + 8), h1 = *reinterpret_cast<const fz_f4*>(bx + 12);
             float lb = 0.f;
 #pragma unroll
             for (int f = 0; f < FL; ++f) {
@@ -359,9 +377,19 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                 m = fmaxf(m - eq[f], 0.f);
                 lb = fmaf(m, m, lb);
             }
-            reach = lb * 0.999999f <= barrow;
+            return __any(lb * 0.999999f <= barrow);
+        };
+        // entering an aligned group of tiles from its near end: if the whole group is out of reach, the scan's pointer on
+        // this side jumps over it (its remaining tiles are never staged)
+        const bool rside = t >= home;
+        if ((rside && (t % FZ_KM_GT) == 0) || (!rside && (t % FZ_KM_GT) == FZ_KM_GT - 1)) {
+            if (!box_reach(cur + 528)) {
+                if (rside) { const int e = (t / FZ_KM_GT + 1) * FZ_KM_GT; nr = nr > e ? nr : e; }
+                else { const int e = (t / FZ_KM_GT) * FZ_KM_GT - 1; nl = nl < e ? nl : e; }
+            }
         }
-        if (__any(reach)) {
+        const bool reach = box_reach(cur + 512);
+        if (reach) {
         fz_f4 nb0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
         fz_f4 nb1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
 #pragma unroll 2
@@ -393,12 +421,13 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         }
         cur_t = nxt_t;
         __syncthreads();
+        return more;
     };
     stage(cur_t, tA);
     __syncthreads();
-    for (int n = 0; n < ntiles; n += 2) {
-        run_tile(tA, tB, n);
-        if (n + 1 < ntiles) run_tile(tB, tA, n + 1);
+    while (true) {
+        if (!run_tile(tA, tB)) break;
+        if (!run_tile(tB, tA)) break;
     }
     for (int R = 0; R < 16; ++R) {
         const int64_t i = __shfl(qi, R, 64);
