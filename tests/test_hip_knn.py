@@ -220,7 +220,8 @@ def test_screened_search_is_the_exact_search(scale, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['ties', 'bound', 'single_set', 'F3', 'F6', 'k40', 'unrelated_sets', 'ragged'])
+@pytest.mark.parametrize('case', ['ties', 'bound', 'single_set', 'F3', 'F6', 'k40', 'unrelated_sets', 'ragged', 'tiny', 'F1', 'F2',
+                                  'flat_feature', 'nan_query', 'clustered'])
 def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     """fz_knn_mfma.h (fp32 MFMA screen, seeds from feature set 0, (distance, index) ordered lists) returns the
     neighbour table of the all-fp64 ascending scan (FZ_KNN_FP64=1) bit for bit: exact duplicates among the models
@@ -235,6 +236,9 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     if case == 'F6': F = 6
     if case == 'k40': k = 40
     if case == 'ragged': M, N = 1000 + 37, 17
+    if case == 'tiny': M, N, k = 10, 3, 4
+    if case == 'F1': F = 1
+    if case == 'F2': F = 2
     base = rs.normal(22.0, 1.0, size=(M, F))
     noise = 0.05
     if case == 'ties':
@@ -243,8 +247,16 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     feats = np.stack([base + rs.normal(0, noise, size=(M, F)) if noise else base for _ in range(K)])
     if case == 'unrelated_sets':
         feats = np.stack([rs.permutation(base) for _ in range(K)])
+    if case == 'flat_feature':
+        feats[:, :, 2] = 21.5                                           # a feature without any spread (bounding box of width 0)
+    if case == 'clustered':                                             # tight far-apart clumps: most tiles lie beyond every bar
+        cen = rs.normal(22.0, 3.0, size=(30, F))
+        base = cen[rs.randint(0, 30, M)] + rs.normal(0, 0.01, size=(M, F))
+        feats = np.stack([base + rs.normal(0, 0.003, size=(M, F)) for _ in range(K)])
     feats = feats.astype(np.float32)
     q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
+    if case == 'nan_query':
+        q[3, 1] = np.nan; q[100] = np.inf
     if case == 'ties':
         q[:50] = feats[0][rs.choice(1000, 50)].astype(np.float64)        # distance exactly 0 to two models each
     if case == 'bound':
@@ -263,6 +275,8 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     np.testing.assert_array_equal(out['mfma'], out['fp64'])
     # the host's own float64 brute force: stable argsort = ascending (distance, index)
     for i in range(0, N, 29):
+        if not np.isfinite(q[i]).all():
+            continue
         for t in range(K):
             d2 = ((q[i][None, :] - feats[t].astype(np.float64)) ** 2).sum(axis=1)
             want = np.argsort(d2, kind='stable')[:k]
