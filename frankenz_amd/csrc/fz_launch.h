@@ -367,7 +367,7 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         {
             const char* e = getenv("FZ_NOLIST");
             int want = e ? atoi(e) : -1;
-            if (want < 0 && n >= 16384) want = fz_nolist_probe<SRC>(c, src, kv, n, M, ko) > 0.27 ? 1 : 0;
+            if (want < 0 && n >= 16384) want = fz_nolist_probe<SRC>(c, src, kv, n, M, ko) > 0.22 ? 1 : 0;
             if (want == 1) {
                 r = fz_launch_nolist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs);
                 if (r <= 0) return r;

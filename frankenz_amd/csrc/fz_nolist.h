@@ -8,14 +8,13 @@
 // chi2 with its mode at chi2 = k, so an object's exact maximum ln-like is decided by two numbers: the
 // largest chi2 at or below the mode and the smallest above it.
 //   pass 1 (k_nl_max):  chi2 of every pair, the two-sided tracking, -> the chi2 of the best model per object;
-//   pass 2 (k_nl_main): chi2 again; the weight relative to the (now known, exact) maximum in fp32 as the screen;
-//                       pairs the screen puts within the threshold form their weight in fp64 -- integer powers by
-//                       multiplication, the half power by a Newton-refined v_rsq_f64, one exp: no log -- apply the
-//                       reference's strict rule w > wt_thresh * max(w) exactly (max(w) is 1 by construction) and add
-//                       the weight straight into the object's LDS histogram (one ds_add_f64; pdf.py:585-622 with the
-//                       per-index kernel mass and the one convolution of kde_finalize).
-// Precision class = k_fused's weight-space body: everything stacked is fp64; the sub-threshold remainder of the
-// evidence sum is fp32 (conftest.EVID).  2 x the chi2 arithmetic, ~0 B/eval of HBM traffic.
+//   pass 2 (k_nl_main): chi2 again; every pair's weight relative to the (now known, exact) maximum in fp64 -- integer
+//                       powers by multiplication, the half power by a Newton-refined v_rsq_f64, one exp: no log; the
+//                       reference's strict rule w > wt_thresh * max(w) (max(w) is 1 by construction) decides what goes
+//                       straight into the object's LDS histogram (one ds_add_f64; pdf.py:585-622 with the per-index
+//                       kernel mass and the one convolution of kde_finalize); every weight enters the evidence sum.
+// All fp64 (the evidence too: unlike k_fused's weight-space body there is no fp32 remainder).  2 x the chi2 arithmetic,
+// ~0 B/eval of HBM traffic.
 // (reference: bruteforce.py:602-631 -> pdf.py:27-100, 585-622)
 #pragma once
 #include "fz_kernels.h"
@@ -43,7 +42,7 @@ __device__ __forceinline__ void nl_stage_tile(const SRC& src, const int32_t* pos
 // ---- which form for this launch?  The share of (object, model) pairs within the weight threshold, measured on
 // a sample of the launch's objects (one wave per sampled object, two sweeps over the models: best chi2 by the
 // two-sided rule of pass 1, then the count).  Lists cost ~40 + 145 f ms per 2.6e10 pairs, the list-free form
-// ~82 ms whatever f is: the launcher switches at f = 0.27.  (The sample: 256 objects x every fourth 64-model
+// ~76 ms whatever f is: the launcher switches at f = 0.22.  (The sample: 256 objects x every fourth 64-model
 // group; the best chi2 of the subsample is a little worse than the true one, which can only raise the estimate.)
 template <class SRC>
 __global__ __launch_bounds__(256) void k_nl_probe(SRC src_, int64_t N, int M, int S, double wt_thresh, const int* __restrict__ omap,
@@ -173,7 +172,6 @@ __global__ __launch_bounds__(NW * 64) void k_nl_main(SRC src_, const KdeView* __
     const KdeView kv = *kvp;
     const int32_t* posw = kv.pos;
     const int w0 = kv.w0;
-    const float thrf = uniform_f((wt_thresh > 0.0) ? (float)(wt_thresh * 0.99) : -1.f);      // fp32 screen: 1 % below the exact threshold
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t slot = gw + rnd * nwaves;
         const bool work = slot < N;
@@ -186,8 +184,7 @@ __global__ __launch_bounds__(NW * 64) void k_nl_main(SRC src_, const KdeView* __
         const double lmax = live ? uniform_d(src.lnl_of_chi2(cref)) : (double)NAN;
         const double crs = live ? ((cref > 0.0) ? cref : 1.0) : 1.0;
         const double rcr = uniform_d(1.0 / crs);
-        const float rcrf = uniform_f((float)rcr);
-        double S = 0.0; float s = 0.f;
+        double S = 0.0;
         nl_stage_tile<SRC, TILE, NT, true>(src, posw, 0, tileA, tid, wave);
         __syncthreads();
         auto run_tile = [&](const double* cur, double* nxt, int t) {
@@ -203,41 +200,33 @@ __global__ __launch_bounds__(NW * 64) void k_nl_main(SRC src_, const KdeView* __
                     src.load_obj_lds(objs, ob);
                     double c2 = src.chi2_of(ob, m);
                     c2 = (j < M) ? c2 : 1e30;                     // pad models: weight 0
-                    const double dc = c2 - cref;                  // fp64 difference, then fp32
-                    const float l2 = __builtin_amdgcn_logf((float)c2 * rcrf);
-                    const float tt = fmaf(l2, 0.5f * WP, (float)dc * -0.72134752f);      // log2 of the weight relative to the best (<= ~0)
-                    const float w32 = __builtin_amdgcn_exp2f(tt);
-                    const bool c = w32 > thrf;
-                    if (__any(c)) {
-                        // exact weight of the screened pairs: (chi2 / cref)^(WP/2) exp(-(chi2 - cref)/2)
-                        const double r = c2 * rcr;
-                        double pw = 1.0;
-                        if constexpr ((WP >> 1) >= 1) pw = r;
-                        if constexpr ((WP >> 1) >= 2) pw = pw * r;
-                        if constexpr ((WP >> 1) >= 3) pw = pw * r;
-                        if constexpr (WP & 1) {                   // r^(1/2) = r * rsqrt(r), one Newton step on the hardware estimate
-                            double y = __builtin_amdgcn_rsq(r);
-                            y = y * fma(-0.5 * r, y * y, 1.5);
-                            y = y * fma(-0.5 * r, y * y, 1.5);
-                            pw = pw * (r * y);
-                        }
-                        const double w = c ? pw * exp_clamped(-0.5 * dc, tb) : 0.0;      // the argument is > 0 for pairs below the mode; bounded because cref is the arg-max
-                        const bool sel = c && (w > wt_thresh);    // strict; max(w) == 1 (pdf.py:591)
-                        if (sel) { unsafeAtomicAdd(&row[tag + w0], w); S += w; }
-                        s += (c && !sel) ? w32 : 0.f;
+                    // weight relative to the best, all fp64: (chi2 / cref)^(WP/2) exp(-(chi2 - cref)/2) -- integer powers by
+                    // multiplication, the half power by a Newton-refined v_rsq_f64, one exp, no log.  (A fp32 screen in front of
+                    // this, as in k_fused, does not pay here: the form only runs when most pairs pass it.)
+                    const double dc = c2 - cref;
+                    const double r = c2 * rcr;
+                    double pw = 1.0;
+                    if constexpr ((WP >> 1) >= 1) pw = r;
+                    if constexpr ((WP >> 1) >= 2) pw = pw * r;
+                    if constexpr ((WP >> 1) >= 3) pw = pw * r;
+                    if constexpr (WP & 1) {                       // r^(1/2) = r * rsqrt(r)
+                        double y = __builtin_amdgcn_rsq(r);
+                        y = y * fma(-0.5 * r, y * y, 1.5);
+                        y = y * fma(-0.5 * r, y * y, 1.5);
+                        pw = pw * ((r > 0.0) ? r * y : 0.0);      // chi2 == 0 (self match): weight 0, as chi2^(k/2) says
                     }
-                    s += c ? 0.f : w32;
+                    const double w = pw * exp_clamped(-0.5 * dc, tb);      // the argument is > 0 for pairs below the mode; bounded because cref is the arg-max
+                    if (w > wt_thresh) unsafeAtomicAdd(&row[tag + w0], w);         // strict; max(w) == 1 (pdf.py:591)
+                    S += w;
                 }
             }
             __syncthreads();
         };
-        int tick = 0;
         for (int t = 0; t < ntiles; t += 2) {
             run_tile(tileA, tileB, t);
             if (t + 1 < ntiles) run_tile(tileB, tileA, t + 1);
-            if ((++tick & 7) == 0) { S += (double)s; s = 0.f; }
         }
-        const double stot = wave_sum(S + (double)s);
+        const double stot = wave_sum(S);
         const double le = lmax + log_pos(stot, tb);
         const bool ok = live && (le - le == 0.0) && stot > 0.0;
         if (work && lane == 0) {
