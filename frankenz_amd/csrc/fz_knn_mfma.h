@@ -3,25 +3,27 @@
 //
 // With q' = fl32(q - c) for a per-set centre c, the squared distance of a query and a model is one
 // 8-slot row-times-column product (F <= 6)
-//     |q' - (p - c)|^2 = [-2 q'_0 .. -2 q'_{F-1}, alpha, 1, 0 ..] . [p_0 .. p_{F-1}, 1, beta, 0 ..]
+//     |q' - (p - c)|^2 - bar = [-2 q'_0 .. -2 q'_{F-1}, alpha - bar, 1, 0] . [p_0 .. p_{F-1}, 1, beta, j]
 //     alpha = |q'|^2 + 2 q'.c      beta = |p - c|^2            (both formed in fp64, rounded once)
-// so a wave forms the 16 x 16 distances of 16 queries and 16 models with two
-// v_mfma_f32_16x16x4_f32 (32 cycles each: 4 distances per cycle and SIMD, against ~1.5 for the
-// packed-fp32 vector form of fz_knn.h).  The model side holds the ORIGINAL float features, so the
-// LDS tile that feeds the matrix pipe also feeds the exact re-check; the centring only lives in
-// alpha / beta and keeps the big |q|^2 + |p|^2 - 2 q.p cancellation out of the fp32 chain.
-// The product is only the SCREEN: it is compared with an admission bar that is provably above the
-// exact k-th distance (bound below), and the pairs that pass recompute their distance in fp64 from
-// the original query and features and go through the same sorted-list insertion as k_knn_query --
-// the neighbour table is the exact fp64 top-k, bit for bit (tests/test_hip_knn.py
-// test_screened_search_is_the_exact_search, tests/test_hip_fullsize.py at M = 1e5, K = 25, k = 20).
+// so a wave forms the 16 x 64 products of 16 queries and 64 models with eight v_mfma_f32_16x16x4_f32, and
+// the SIGN of a product says whether the pair is under the query's admission bar.  The model side holds the
+// ORIGINAL float features (and, in the slot the query side multiplies by 0, the model's original index), so
+// the LDS tile that feeds the matrix pipe also feeds the exact re-check; the centring only lives in alpha /
+// beta and keeps the big |q|^2 + |p|^2 - 2 q.p cancellation out of the fp32 chain.
+// The product is only the SCREEN: the bar is provably above the exact k-th distance (bound below), and the
+// pairs under it recompute their distance in fp64 from the original query and features and enter the
+// query's sorted list (LDS, ordered by (distance, original index)) -- the neighbour table is the exact fp64
+// top-k, bit for bit, whatever the visiting order (tests/test_hip_knn.py
+// test_matrix_pipe_search_is_the_exact_search, tests/test_hip_fullsize.py at M = 1e5, K = 25, k = 20).
+// Around that: seeds from feature set 0, models and queries in Morton order with an outward scan from the
+// queries' own place, and tiles / groups of tiles skipped by bounding box (comments at k_knn_mfma).
 //
 // Bar.  u = 2^-24, Q = |q'|, P = max_p |p - c|, C = |c|.  Without rounding the product is
-// |q' - (p - c)|^2 + e_a alpha + e_b beta (|e| <= u), and | |q' - (p - c)| - |q - p| | <= u Q; the 8-term
-// fma chain of the matrix pipe adds at most 8 u sum |a_k b_k| <= 8 u (2 Q (P + C) + |alpha| + beta) (16 u is
-// budgeted, in case the pipe truncates).  Hence  |q - p|^2 < tau  implies
-//     fl(product) < tau + 2 sqrt(tau) u Q + u (18 Q^2 + 18 P^2 + 68 Q C + 32 Q P),
-// which (slack terms times 1.01, every float operation rounded up) is the bar.
+// |q' - (p - c)|^2 - bar + e_a (alpha - bar) + e_b beta (|e| <= u), and | |q' - (p - c)| - |q - p| | <= u Q; the
+// 8-term fma chain of the matrix pipe adds at most 8 u sum |a_k b_k| <= 8 u (2 Q (P + C) + |alpha| + bar + beta)
+// (16 u is budgeted, in case the pipe truncates).  Hence  |q - p|^2 <= tau  implies  fl(product) < 0  for
+//     bar = (tau + 2 sqrt(tau) u Q + u (19 Q^2 + 18 P^2 + 70 Q C + 32 Q P)) (1 + 2e-6),
+// slack terms times 1.01, every float operation rounded up (knn_bar_mfma).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
