@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FRANKENZ_HIP_LIB",
 class LikeOpts(C.Structure):
     _fields_ = [("free_scale", C.c_int32), ("ignore_model_err", C.c_int32),
                 ("dim_prior", C.c_int32), ("max_iter", C.c_int32),
-                ("ltol", C.c_double)]
+                ("ltol", C.c_double), ("exact_evidence", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class KdeOpts(C.Structure):

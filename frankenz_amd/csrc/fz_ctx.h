@@ -63,6 +63,7 @@ struct fz_ctx {
     int64_t ws_limit = (int64_t)32 << 30;
     int cu_count = 256;
     int force_twopass = 0;     // diagnostics: disable the single-pass fused kernel
+    int exact_evidence = 0;    // every weight of the fused path's ln-evidence in fp64 (fz_like_opts.exact_evidence of the call being served)
 
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;

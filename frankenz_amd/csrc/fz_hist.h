@@ -1,0 +1,414 @@
+// k_hist: fused fit_predict in ONE pass over the models with nothing handed through HBM.
+// (single dictionary kernel, dimensionality prior on, mask-free exact band counts: the weight-space
+//  conditions of k_fused -- every demo configuration of the reference; bruteforce.py:602-631 ->
+//  pdf.py:27-100 / 171-235, 585-622)
+//
+// k_fused records every model within the weight threshold of the RUNNING best in per-object lists in
+// HBM (16 B out, 16 B back: 3.9 B per pair at SDSS depth against 0.06 B algorithmic) and stacks them
+// after the model loop, when every wave of the CU sits in the same latency-bound list walk.  Two facts
+// remove the lists:
+//   (1) the dimensionality-prior likelihood chi2^(k/2) e^(-chi2/2) / C has its maximum at chi2 = k
+//       whatever the data are, so ln L(k) is an upper bound of every ln-like of every object and can
+//       serve as THE reference of every weight: w = L(chi2) / L(k) <= 1.  No re-basing, no overflow
+//       case; objects whose best weight falls out of fp32's range are handed to the exact ln-space
+//       sweep (k_fused<.., false>), as before.
+//   (2) the reference stacks the models with w > wt_thresh * max(w) (pdf.py:591).  max(w) <= 1, so
+//       w > wt_thresh is SUFFICIENT to be stacked and can be decided the moment the pair is seen: its
+//       weight goes straight into the object's LDS histogram (one ds_add_f64 at the label index, the
+//       single-kernel form of the stack).  Only the pairs with wt_thresh * (running best) < w <=
+//       wt_thresh -- a thin band when the best model fits well -- wait in a short per-object list
+//       for the exact maximum.
+// The exact (fp64) weight of a candidate costs ~20 instructions; 7 % of the pairs need it at SDSS depth.
+// A lane that computes it on the spot makes its whole wave pay, so candidates (chi2, label index) are
+// first compacted into a per-object LDS ring and the ring is drained 64 entries at a time by ALL lanes:
+// exact weight, exact evidence share, best chi2 on either side of the mode (the exact maximum, as in
+// k_nl_max), histogram add or the ambiguous list.  The drain's latency overlaps the model loop of
+// the other waves instead of forming a phase of its own.
+// What is fp32: the screening weight and the sum of the NON-candidates (each below wt_thresh of the
+// running best) -- as in k_fused's weight-space body.  EXACT = true computes every pair's weight in
+// fp64 (the all-fp64 evidence; also the form for broad likelihoods, where most pairs are candidates).
+//
+// Mode B (free scale): SCRB screens with the closed form chi2 = A - inter^2 / shape (A = sum x^2/var,
+// one reciprocal) and the drain re-evaluates the reference's residual form sum (x - s y)^2 / var
+// (pdf.py:188-189) from the model record -- the ring then carries the model number, and the label index
+// is read beside the record.  Every chi2 that reaches an output is the exact one; a training-set
+// self match still gives chi2 == 0 exactly.
+#pragma once
+#include <type_traits>
+#include "fz_kernels.h"
+#include "fz_nolist.h"
+
+namespace fz {
+
+// exp(x) for |x| <= 700 with a 256-entry table (2 KB: what the LDS has left beside 16 histogram rows, the rings and the
+// model tiles): n = round(x 256 / ln 2) read off the low mantissa word as in exp_core, r = x - n ln2 / 256 (|r| <= 1.4e-3),
+// exp(r) by the degree-5 Taylor polynomial (remainder 9e-21), 2^(n mod 256 / 256) from the table, 2^(n div 256) into the
+// exponent field.  Same error bound as exp_core (tests/test_hip_fastmath.py covers both).
+#define FZ_HEXP_K 256
+#ifndef FZ_HIST_REFRESH
+#define FZ_HIST_REFRESH 32     // steps between two updates of the candidate bar (and flushes of the fp32 partial sums)
+#endif
+__device__ __forceinline__ double exp_small_tab(double x, const double* __restrict__ tab) {
+    const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
+    x = vmin_raw(vmax_raw(x, -700.0), 700.0);                     // also maps NaN -> -700
+    const double d = fma(x, 369.3299304675746, MAGIC);           // 256 / ln 2
+    const double r = fma(d - MAGIC, -0.0027076061740622863, x);  // ln 2 / 256
+    const int n = __double2loint(d);
+    const double t = tab[n & (FZ_HEXP_K - 1)];
+    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = t * p;                                      // in [1,2)
+    return __hiloint2double(__double2hiint(v) + ((n >> 8) << 20), __double2loint(v));
+}
+
+// w = L(chi2) / L(K) = (chi2 / K)^(K/2) exp(-(chi2 - K) / 2), all fp64: integer powers by multiplication,
+// the half power by a Newton-refined v_rsq_f64, one exp, no log
+template <int WP, bool SMALL = false>
+__device__ __forceinline__ double hist_exactw(double c2, const FastTabs& tb) {
+    constexpr double K = (double)WP;
+    const double r = c2 * (1.0 / K);
+    double pw = 1.0;
+    if constexpr ((WP >> 1) >= 1) pw = r;
+    if constexpr ((WP >> 1) >= 2) pw = pw * r;
+    if constexpr ((WP >> 1) >= 3) pw = pw * r;
+    if constexpr (WP & 1) {
+        double y = __builtin_amdgcn_rsq(r);
+        y = y * fma(-0.5 * r, y * y, 1.5);
+        y = y * fma(-0.5 * r, y * y, 1.5);
+        pw = pw * ((r > 0.0) ? r * y : 0.0);              // chi2 == 0 (self match): weight 0
+    }
+    return pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+}
+
+// wave-wide maximum of a float without the LDS pipe: DPP within rows of 16 lanes, then the four row results through scalar
+// registers; the result is wave-uniform (lanes hold the same SGPR-fed value)
+__device__ __forceinline__ float wave_maxf_dpp(float v) {
+    int x = __float_as_int(v);
+    auto mx = [](int a, int b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__int_as_float(a)), "v"(__int_as_float(b))); return __float_as_int(r); };
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(x, 0)), b = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(x, 32)), d = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+template <int TW>
+struct HistState {
+    double S[TW];            // per lane: fp64 sum of the non-candidates (flushed from s)
+    double Sc[TW];           // per lane: exact weights of the drained candidates
+    double lo[TW], hi[TW];   // per lane: largest chi2 <= K, smallest chi2 > K among the drained candidates
+    float s[TW], tmax[TW];   // per lane: non-candidate sum since the last flush; largest log2 weight seen
+    float tthr[TW];          // wave-uniform: candidates have log2 w above this
+    int pend[TW];            // wave-uniform: entries waiting in the object's candidate buffer
+    int namb[TW];            // wave-uniform: entries in the ambiguous list
+    int tick, next;
+};
+
+// SCRB: chi2 screen of the free scale, A - inter^2 / shape; obx = x / var per band, A = sum x^2 / var
+template <class SRC>
+__device__ __forceinline__ double hist_screen_b(const typename SRC::OR& o, const typename SRC::MR& m, const double (&xiv)[SRC::NB], double A) {
+    double inter = 0.0, shape = 0.0;
+#pragma unroll
+    for (int b = 0; b < SRC::NB; ++b) {
+        inter = fma(m.y[b], xiv[b], inter);
+        shape = fma(m.y[b] * o.v[b], m.y[b], shape);
+    }
+    const double rc = rcp_nr<1>(shape);
+    return fma(-inter * rc, inter, A);
+}
+
+template <class SRC, int TW, int NW, bool EXACT, bool SCRB>
+__global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
+                                                   double wt_thresh, int normalize, Cand* __restrict__ amb, int64_t cap,
+                                                   double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs,
+                                                   const int* __restrict__ omap, int* __restrict__ redo) {
+    constexpr int TILE = 256, RW = SRC::RW, TDR = RW * TILE, TD = TDR + TILE / 2, NT = NW * 64, OD = SRC::OBJ_DOUBLES;
+    constexpr int WP = SRC::WPOW, BT = SRC::NB;
+    constexpr double K = (double)WP;
+    constexpr int NOBJ = NW * TW;
+    constexpr int CAP = 128, DTHR = CAP - 64;                             // ring entries per object; drain from DTHR pending entries on
+    using tag_t = typename std::conditional<SCRB, int32_t, uint16_t>::type;   // label index (< 65536, checked by the launcher) or model number
+    static_assert(WP >= 1 && WP <= 6, "chi2^(1/2) ... chi2^3");
+    __shared__ __attribute__((aligned(16))) double tileA[TD];
+    __shared__ __attribute__((aligned(16))) double tileB[TD];
+    __shared__ __attribute__((aligned(16))) double s_c2[EXACT ? 2 : NOBJ * CAP];
+    __shared__ tag_t s_tag[EXACT ? 2 : NOBJ * CAP];
+    // EXACT has no rings and keeps the full log / exp tables in LDS (every pair takes an exp); the screen form a 256-entry exp table
+    __shared__ __attribute__((aligned(16))) double s_tabs[EXACT ? FZ_TABS_DOUBLES : FZ_HEXP_K];
+    __shared__ __attribute__((aligned(16))) double s_objs[NOBJ * OD];
+    extern __shared__ double s_rows[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * NW, gw = (int64_t)blockIdx.x * NW + wave;
+    const int64_t ngroups = (N + TW - 1) / TW, nrounds = (ngroups + nwaves - 1) / nwaves;
+    const int ntiles = (M + TILE - 1) / TILE;
+    SRC src = src_;
+    src.tb = global_tabs();                                       // finish (log of the evidence, the ambiguous band): through the vector L1
+    const FastTabs tb = src.tb;
+    FastTabs tbx;                                                 // what hist_exactw reads in the model loop
+    if constexpr (EXACT) tbx = stage_tabs(s_tabs, tid, NT);
+    else {
+        for (int k = tid; k < FZ_HEXP_K; k += NT) s_tabs[k] = FZ_EXP_TAB[k * (FZ_EXP_K / FZ_HEXP_K)];
+        tbx.logt = nullptr; tbx.expt = s_tabs;
+    }
+    const KdeView kv = *kvp;
+    const int32_t* posw = kv.pos;
+    const int w0 = kv.w0;
+    double* objs = s_objs + wave * (TW * OD);
+    double* rows = s_rows + (size_t)wave * TW * acc_stride;
+    double* rc2 = s_c2 + (EXACT ? 0 : wave * (TW * CAP));
+    tag_t* rtag = s_tag + (EXACT ? 0 : wave * (TW * CAP));
+    Cand* ambw = amb + (size_t)gw * TW * cap;
+    // log2 of the screening weight: t = (K/2) log2(chi2) - (chi2 - K) log2(e) / 2 - (K/2) log2(K)
+    const float T0 = (float)(-0.5 * K * log2(K));
+    const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh * 0.99) : -INFINITY;       // the fp32 screen keeps a 1 % margin
+    const double thr_def = wt_thresh * (1.0 + 1e-3);              // above this a weight is stacked whatever the maximum turns out to be
+    const double lref = uniform_d(src.lnl_of_chi2(K));            // ln L at the mode: the reference of every weight
+
+    for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
+        const int64_t g = gw + rnd * nwaves;
+        const bool work = g < ngroups;                            // wave-uniform
+        const int64_t i0 = work ? g * TW : 0;
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            const int64_t os = i0 + o < N ? i0 + o : N - 1;
+            src.park_obj(omap ? (int64_t)omap[os] : os, objs + o * OD, lane);
+        }
+        for (int k = lane; k < TW * acc_stride; k += 64) rows[k] = 0.0;
+        nl_stage_tile<SRC, TILE, NT, true>(src, posw, 0, tileA, tid, wave);
+        __syncthreads();
+        // the wave's objects stay in VGPRs for the whole model loop (an LDS broadcast read: the compiler
+        // cannot tell that they are wave-uniform and keeps them out of the scalar file)
+        typename SRC::OR ob[TW];
+        double xiv[TW][BT], Aq[TW];
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            src.load_obj_lds(objs + o * OD, ob[o]);
+            if constexpr (SCRB) {
+                Aq[o] = 0.0;
+#pragma unroll
+                for (int b = 0; b < BT; ++b) { xiv[o][b] = ob[o].x[b] * ob[o].v[b]; Aq[o] = fma(xiv[o][b], ob[o].x[b], Aq[o]); }
+            }
+        }
+        HistState<TW> hs;
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
+            hs.tthr[o] = -120.f; hs.pend[o] = 0; hs.namb[o] = 0;
+        }
+        hs.tick = 0; hs.next = 1;
+
+        // one candidate (exact chi2, label index, all lanes of `act`): evidence share, best chi2 on either
+        // side of the mode, histogram add or ambiguous list
+        auto settle = [&](int o, bool act, double c2, int tag) {
+            const double w = act ? hist_exactw<WP, !EXACT>(c2, tbx) : 0.0;
+            hs.Sc[o] += w;
+            const bool below = c2 <= K;
+            hs.lo[o] = vmax_raw(hs.lo[o], (act && below) ? c2 : -INFINITY);
+            hs.hi[o] = vmin_raw(hs.hi[o], (act && !below) ? c2 : INFINITY);
+            if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + tag + w0], w);
+            const bool am = act && !(w > thr_def);
+            const unsigned long long mask = __ballot(am);
+            if (mask) {                                           // wave-uniform
+                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                hs.namb[o] += __builtin_popcountll(mask);
+            }
+        };
+        // settle the first (up to) 64 entries of object o's buffer with all lanes; what lies behind them moves to the front
+        auto drain = [&](int o) {
+            const int n = hs.pend[o] < 64 ? hs.pend[o] : 64;
+            double c2 = rc2[o * CAP + lane];
+            int tag = (int)rtag[o * CAP + lane];
+            const int rest = hs.pend[o] - n;                      // < 64
+            if (rest > 0) {                                       // wave-uniform
+                const double c2b = rc2[o * CAP + 64 + lane];
+                const tag_t tgb = rtag[o * CAP + 64 + lane];
+                if (lane < rest) { rc2[o * CAP + lane] = c2b; rtag[o * CAP + lane] = tgb; }
+            }
+            const bool act = lane < n;
+            if constexpr (SCRB) {
+                // the buffer holds the model number: exact residual-form chi2 from the record (pdf.py:181-189)
+                const int j = act ? tag : 0;
+                typename SRC::MR m;
+                src.load_model_rec16(j, m);
+                tag = posw[j];
+                c2 = src.chi2_of(ob[o], m);
+            }
+            settle(o, act, c2, tag);
+            hs.pend[o] = rest;
+        };
+
+        auto run_tile = [&](const double* cur, double* nxt, int t, auto tailc) {
+            constexpr bool TAIL = decltype(tailc)::value;
+            if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave);
+            if (work) {
+                const int32_t* tags = reinterpret_cast<const int32_t*>(cur + TDR);
+                // the next step's record is requested before the current one is used
+                typename SRC::MR mn;
+                int tagn = 0;
+                src.template load_model_lds<TILE>(cur, lane, mn);
+                if (!SCRB) tagn = tags[lane];
+#pragma unroll
+                for (int st = 0; st < TILE / 64; ++st) {
+                    const int j = t * TILE + st * 64 + lane;
+                    const typename SRC::MR m = mn;
+                    int ptag = tagn;
+                    asm volatile("" : "+v"(ptag));                // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
+                    if (st + 1 < TILE / 64) {
+                        src.template load_model_lds<TILE>(cur, (st + 1) * 64 + lane, mn);
+                        if (!SCRB) tagn = tags[(st + 1) * 64 + lane];
+                    }
+                    double c2[TW];
+#pragma unroll
+                    for (int o = 0; o < TW; ++o) {
+                        c2[o] = SCRB ? hist_screen_b<SRC>(ob[o], m, xiv[o], Aq[o]) : src.chi2_of(ob[o], m);
+                        if (TAIL) c2[o] = (j < M) ? c2[o] : 1e30;   // pad lanes: weight 0
+                    }
+                    if constexpr (EXACT) {
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            // every pair in fp64; the running best (of the exact weights) bounds what can still be stacked
+                            const bool valid = !TAIL || j < M;
+                            const double w = valid ? hist_exactw<WP, false>(c2[o], tbx) : 0.0;
+                            hs.S[o] += w;
+                            const bool up = w > hs.Sc[o];           // (EXACT: Sc holds the lane's best weight so far, lo its chi2)
+                            hs.Sc[o] = up ? w : hs.Sc[o];
+                            hs.lo[o] = up ? c2[o] : hs.lo[o];
+                            if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag + w0], w);
+                            const bool am = valid && !(w > thr_def) && (w >= wt_thresh * 0.999 * hs.Sc[o]);
+                            const unsigned long long mask = __ballot(am);
+                            if (mask) {
+                                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                                if (am) { Cand e; e.lnl = c2[o]; e.j = ptag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                                hs.namb[o] += __builtin_popcountll(mask);
+                            }
+                        }
+                        if ((++hs.tick & 15) == 0) {
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) hs.Sc[o] = wave_max(hs.Sc[o]);
+                        }
+                    } else {
+                        float tl[TW];
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            const float cf = (float)c2[o];
+                            const float l2 = __builtin_amdgcn_logf(cf);                 // chi2 == 0: -inf; a negative screen value: nan
+                            const float df = (float)(c2[o] - K);                        // fp64 difference, then fp32
+                            const float tt = fmaf(l2, 0.5f * WP, fmaf(df, -0.72134752f, T0));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(tl[o]) : "v"(tt), "v"(-200.f));   // nan / -inf -> -200: no weight
+                        }
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            const float w = __builtin_amdgcn_exp2f(tl[o]);
+                            const bool c = tl[o] > hs.tthr[o];
+                            asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[o]));
+                            hs.s[o] += c ? 0.f : w;
+                            // candidates -> the object's ring (ballot + mbcnt compaction); positions are wave-uniform scalars
+                            const unsigned long long mask = __ballot(c);
+                            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            const int slot = hs.pend[o] + pre;      // < 64 wait when a step begins, a step adds at most 64: never past CAP
+#if !defined(FZ_DIAG_NOAPPEND)
+                            if (c) { rc2[o * CAP + slot] = c2[o]; rtag[o * CAP + slot] = (tag_t)(SCRB ? j : ptag); }
+#endif
+                            hs.pend[o] += __builtin_popcountll(mask);
+                        }
+                        if (++hs.tick == hs.next) {                                   // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
+                            hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) {
+                                hs.S[o] += (double)hs.s[o]; hs.s[o] = 0.f;
+                                const float mx = wave_maxf_dpp(hs.tmax[o]);
+                                hs.tmax[o] = mx;
+                                hs.tthr[o] = fmaxf(mx + lthr2, -120.f);
+                            }
+                        }
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+#if defined(FZ_DIAG_NODRAIN)
+                            if (hs.pend[o] >= DTHR) { hs.pend[o] -= 64; }
+#else
+                            while (hs.pend[o] >= DTHR) drain(o);
+#endif
+                        }
+                    }
+                }
+            }
+#if !defined(FZ_DIAG_NOBARRIER)
+            __syncthreads();
+#endif
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            if (t + 1 < ntiles) run_tile(tileA, tileB, t, std::false_type{}); else run_tile(tileA, tileB, t, std::true_type{});
+            if (t + 1 < ntiles) {
+                if (t + 2 < ntiles) run_tile(tileB, tileA, t + 1, std::false_type{}); else run_tile(tileB, tileA, t + 1, std::true_type{});
+            }
+        }
+
+        // finish: what is left in the rings, the exact maximum, the evidence, the ambiguous entries, the PDF
+        if (work) {
+#pragma unroll 1
+            for (int o = 0; o < TW; ++o) {
+                if (i0 + o >= N) break;
+                const int64_t i = omap ? (int64_t)omap[i0 + o] : i0 + o;
+                double* row = rows + o * acc_stride;
+                double wbest_run = 0.0;
+                if constexpr (!EXACT) {
+                    while (hs.pend[o] > 0) drain(o);
+                } else {
+                    wbest_run = wave_max(hs.Sc[o]);
+                }
+                double lbest;                                                  // exact ln-like of the best model
+                if constexpr (EXACT) {
+                    // the lane that holds the wave-wide best weight names the best model's chi2
+                    const unsigned long long who = __ballot(hs.Sc[o] == wbest_run && wbest_run > 0.0);
+                    const int src_lane = who ? __builtin_ctzll(who) : 0;
+                    const double cb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hs.lo[o]), src_lane),
+                                                       __builtin_amdgcn_readlane(__double2loint(hs.lo[o]), src_lane));
+                    lbest = who ? uniform_d(src.lnl_of_chi2(cb)) : -INFINITY;
+                } else {
+                    const double l = wave_max(hs.lo[o]), h = -wave_max(-hs.hi[o]);
+                    const double ll = (l >= 0.0) ? src.lnl_of_chi2(l) : -INFINITY;
+                    const double lh = (h < 1e299) ? src.lnl_of_chi2(h) : -INFINITY;
+                    lbest = uniform_d(fmax(ll, lh));
+                }
+                const double stot = EXACT ? wave_sum(hs.S[o]) : wave_sum(hs.Sc[o]) + wave_sum(hs.S[o] + (double)hs.s[o]);
+                const double le = lref + log_pos(stot, tb);
+                const float tm = EXACT ? 0.f : wave_maxf(hs.tmax[o]);
+                // no candidate at all, an evidence that is not a number, or a best weight so far below the mode
+                // that the fp32 remainder has lost terms (2^-126 / 2^-80: still 2^-46 below the best): the exact ln-space sweep decides
+                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f));
+                // the ambiguous band, by the reference's own rule (pdf.py:591) with the exact maximum and evidence
+                const int na = __builtin_amdgcn_readfirstlane(hs.namb[o]);
+                if (na > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // entries were written by other lanes of this wave
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const double thr = wt_thresh * exp_neg(lbest - le, tb);     // wt_thresh * max(wt)
+                    const Cand* cb = ambw + (size_t)o * cap;
+                    for (int c0 = 0; c0 < na; c0 += 64) {
+                        const int k = c0 + lane;
+                        const bool in1 = k < na;
+                        const Cand e1 = cb[in1 ? k : 0];
+                        const double l1 = in1 ? src.lnl_of_chi2(e1.lnl) : -INFINITY;
+                        const bool s1 = in1 && (exp_neg(l1 - le, tb) > thr);   // strict
+                        if (s1) unsafeAtomicAdd(&row[e1.j + w0], hist_exactw<WP>(e1.lnl, tb));
+                    }
+                }
+                if (lane == 0) {
+                    if (lmap) lmap[i] = lbest;
+                    if (levid) levid[i] = le;
+                    if (!ok) redo[1 + atomicAdd(redo, 1)] = (int)i;
+                }
+                kde_finalize<true>(kv, row, ok, normalize, pdfs + i * kv.G, lane, ok ? 1.0 / stot : 1.0, true);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace fz

@@ -17,7 +17,14 @@ using namespace fz;
 // VAR_FAST exists only when BT can equal the real band count (B in 4..8): padded band
 // counts always carry mask bits.
 #define FZ_EXACT_BT (FZ_BT >= 4 && FZ_BT <= 8)
-#if FZ_EXACT_BT
+#if defined(FZ_DEV_FAST)
+// development builds (tools/devbuild.sh): the mask-free variant only, no ln-prior instantiations -- a quarter of the compile time
+#define FZ_SWITCH_VAR(MODE_, CALL)                                         \
+    switch (var) {                                                         \
+        case 0: { CALL(FZ_BT, MODE_, 0); } break;                          \
+        default: return fail(-1, "FZ_DEV_FAST build: variant %d not compiled", var); \
+    }
+#elif FZ_EXACT_BT
 #define FZ_SWITCH_VAR(MODE_, CALL)                                         \
     switch (var) {                                                         \
         case 0: { CALL(FZ_BT, MODE_, 0); } break;                          \
@@ -68,6 +75,11 @@ int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n
 int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n, const fz_kde_opts* ko, double* lmap,
                               double* levid, double* pdfs) {
     const int64_t M = c->M;
+#if defined(FZ_DEV_FAST)
+#define FZ_CALL_FUSED(BT_, MODE_, VAR_)                                                                   \
+    PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
+    return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
+#else
 #define FZ_CALL_FUSED(BT_, MODE_, VAR_)                                                                   \
     if (c->prior.tab) {                                                                                    \
         PhotSrc<BT_, MODE_, VAR_, true> ph; ph.mv = model_view(c); ph.ov = obj_view(c);                    \
@@ -76,6 +88,7 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
     }                                                                                                      \
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
+#endif
     FZ_SWITCH(FZ_CALL_FUSED)
     return 0;
 }

@@ -4,6 +4,7 @@
 #include "fz_kernels.h"
 #include "fz_ol.h"
 #include "fz_nolist.h"
+#include "fz_hist.h"
 
 inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
     using namespace fz;
@@ -229,9 +230,11 @@ template <class SRC>
 constexpr bool fz_has_wspace() {
     return SRC::WPOW >= 1 && SRC::WPOW <= 6 && (SRC::LMODE != 2 || SRC::NB <= 5) && (SRC::NB < 7 || SRC::LMODE == 1);
 }
+// exact_evidence of the call being launched (fz_launch_fitpredict sets it): the fp32-remainder bodies are not used
+inline bool& fz_exact_now() { static thread_local bool v = false; return v; }
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
-    if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE");
+    if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE") && !fz_exact_now();
     return false;
 }
 template <class SRC, int TW, int NW>
@@ -314,6 +317,86 @@ int fz_launch_nolist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     }
 }
 
+// single pass with in-kernel LDS histograms and no candidate lists (fz_hist.h); +1 = not applicable / does not fit.
+// exact: every weight in fp64 (the all-fp64 evidence, and the form for broad likelihoods)
+template <class SRC, int TW, int NW, bool EXACT, bool SCRB>
+int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                     double* lmap, double* levid, double* pdfs) {
+    constexpr int SW = 4;
+    auto kern = fz::k_hist<SRC, TW, NW, EXACT, SCRB>;
+    const size_t lds = (size_t)NW * TW * kv.acc_stride * 8;
+    {
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void*)kern));
+        if (fa.sharedSizeBytes + lds > 160 * 1024) return 1;
+    }
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, lds));
+    bpc = std::max(1, bpc);
+    const int64_t groups = (n + TW - 1) / TW;
+    const int64_t need = (groups + NW - 1) / NW;
+    const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);        // the ambiguous lists can never overflow (cap = M); only what is used is touched
+    const int64_t fit = (int64_t)(c->ws_limit / (per_wave * NW));
+    int64_t blocks = need;
+    if (need > c->cu_count) {
+        const int64_t k = std::min<int64_t>(bpc, fit / c->cu_count);
+        if (k >= 1) blocks = std::min<int64_t>(need, k * c->cu_count);
+        else if (fit >= c->cu_count / 2) blocks = fit;
+        else return 1;
+    } else if (fit < need) return 1;
+    const size_t sweep_ws = (size_t)c->cu_count * SW * M * sizeof(fz::Cand);
+    if (c->d_cand.ensure(std::max((size_t)blocks * NW * per_wave, sweep_ws)) != 0) return 1;
+    FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(c->d_redo.p, 0, sizeof(int), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
+    Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
+                       (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs, c->omap, c->d_redo.as<int>());
+    {
+        // sweep: the exact ln-space body over the objects handed back (count on the device)
+        auto sweep = fz::k_fused<SRC, 1, SW, false, true>;
+        constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
+        const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
+        if (fa.sharedSizeBytes + lds2 <= 160 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>(c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, src,
+                               c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
+                               lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class SRC>
+int fz_launch_hist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                   double* lmap, double* levid, double* pdfs, bool exact) {
+    if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 6)) return 1;
+    else {
+        if (!src.lp.dim_prior || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31)) return 1;
+        int tw = 1, nw = 16;
+        if (const char* e = getenv("FZ_HIST_CFG")) sscanf(e, "%d,%d", &tw, &nw);
+        constexpr bool SB = (SRC::LMODE == 2);
+        const bool scrb = SB && !getenv("FZ_HIST_NOSCRB");
+        if (exact) {
+            if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            return fz_launch_hist_g<SRC, 2, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        }
+        if constexpr (SB) {
+            if (scrb) {
+                if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                return fz_launch_hist_g<SRC, 2, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            }
+        }
+        if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        return fz_launch_hist_g<SRC, 2, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+    }
+}
+
 // object-per-lane single pass (fz_ol.h); +1 = does not fit, caller takes the k_fused route
 template <class SRC, int OPL>
 int fz_launch_ol(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
@@ -361,6 +444,14 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int r = 1;
+        // the default where it applies: one pass, LDS histograms, no candidate lists (fz_hist.h); FZ_HIST=0 keeps k_fused,
+        // FZ_EXACT_EVIDENCE=1 (or like_opts.exact_evidence) the all-fp64 form
+        const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
+        fz_exact_now() = exact;
+        if (!getenv("FZ_HIST") || atoi(getenv("FZ_HIST")) != 0) {
+            r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact);
+            if (r <= 0) return r;
+        }
         // broad likelihoods run without candidate lists (fz_nolist.h: two passes over the models, nothing in HBM).  The
         // share of pairs within the weight threshold is measured on 256 sampled objects of the launch; FZ_NOLIST=1 / 0
         // forces / forbids the form (launches below 16 384 objects keep the lists unless forced)

@@ -9,7 +9,9 @@ import numpy as np
 from . import _lib
 from ._lib import KdeOpts, LikeOpts, Prior, Timing, check, ptr
 
-_LIKE_KEYS = ("free_scale", "ignore_model_err", "dim_prior", "ltol", "return_scale")
+# the reference's logprob keywords + one extension: exact_evidence=True sums every weight of the fused path's
+# ln-evidence in fp64 (default: the weights below wt_thresh of the best are summed in fp32, ~1e-9 on levid)
+_LIKE_KEYS = ("free_scale", "ignore_model_err", "dim_prior", "ltol", "return_scale", "exact_evidence")
 
 
 def like_opts(lprob_kwargs, max_iter=0):
@@ -23,7 +25,7 @@ def like_opts(lprob_kwargs, max_iter=0):
     return LikeOpts(int(bool(kw.get("free_scale", False))),
                     int(bool(kw.get("ignore_model_err", False))),
                     int(bool(kw.get("dim_prior", True))), int(max_iter),
-                    float(kw.get("ltol", 1e-4)))
+                    float(kw.get("ltol", 1e-4)), int(bool(kw.get("exact_evidence", False))), 0)
 
 
 def kde_opts(kde_kwargs, normalize=True):

@@ -43,6 +43,12 @@ typedef struct fz_like_opts {
     int32_t max_iter;         /* guard for the unbounded loop at pdf.py:199;
                                  <=0 means 10000.  Hitting it is an error.   */
     double  ltol;             /* pdf.py:199  ltol              (default 1e-4) */
+    int32_t exact_evidence;   /* extension (no reference counterpart, default 0): 1 = every weight of the
+                                 fused path's ln-evidence is formed and summed in fp64 (the reference's
+                                 logsumexp, bruteforce.py:619, is fp64 throughout).  0 = the default bodies
+                                 sum the weights BELOW wt_thresh of the best in fp32 (~1e-9 relative on
+                                 levid; lmap, PDFs and every stacked weight are fp64 either way).        */
+    int32_t reserved_;        /* keep 0 */
 } fz_like_opts;
 
 /* kde_kwargs of gauss_kde / gauss_kde_dict (pdf.py:444-445, 529-531). */
