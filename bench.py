@@ -12,11 +12,14 @@ models x 5 bands -> N_obj PDFs on the 701-point redshift grid.  Default workload
 BASELINE.json's headline configuration (1e6 x 1e5 x 5, config index 2).  Inputs are
 synthetic (SURVEY.md section 8d generator) and already resident in HBM when the timed
 region starts; outputs stay in HBM.  Multi-GPU (north_star): the N_obj axis of the SAME
-workload is sharded over the ranks in contiguous blocks (strong scaling: 1e6 objects in
-total), models / labels / dictionary are replicated, and every step ends with the RCCL
-all-gather of the (N/P, 701) PDF shards over xGMI, inside the timed region; compute and
-gather times are reported separately.  --scaling weak gives every rank the full batch
-instead, --no-gather leaves the collective out.
+workload is sharded over the ranks (strong scaling: 1e6 objects in total), models / labels /
+dictionary are replicated, and the step is the library's own multi-GPU call,
+frankenz_amd.sharded.sharded_fit_predict: objects dealt out block-cyclically in --chunks
+rounds, each round's PDF rows written by the kernel straight into the full (N, 701) device
+array and all-gathered in place over xGMI (RCCL, async) while the next round is computed.
+The gather is inside the timed region; compute time and the exposed (not hidden) gather time
+are reported separately.  --scaling weak gives every rank --nobj objects, --no-gather leaves
+the collective out.  bench.py holds no collective code of its own.
 
 Rank 0 prints ONE JSON line.
 """
@@ -144,6 +147,7 @@ def main():
                     help="strong (default): --nobj objects IN TOTAL, sharded over the ranks.  weak: --nobj objects per rank")
     ap.add_argument("--no-gather", action="store_true", help="leave the RCCL all-gather of the PDF shards out of the step")
     ap.add_argument("--gather", action="store_true", help="(default for N > 1; kept for compatibility)")
+    ap.add_argument("--chunks", type=int, default=4, help="rounds per step of the overlapped all-gather (N > 1)")
     ap.add_argument("--workload", choices=["fit_predict", "fit", "predict", "knn", "summarize"], default="fit_predict",
                     help="fit_predict: headline fused path (default). fit: materialising BruteForce.fit "
                          "planes (BASELINE configs[1] when --nobj 100000 --nmodel 10000). predict: "
@@ -169,6 +173,7 @@ def main():
                     help="const: every label carries sigma_z = 0.05 (one dictionary kernel: the histogram + one "
                          "convolution path; every demo of the reference).  varying: sigma_z = U(0.01, 0.1) per model "
                          "(many dictionary kernels: each selected model's window is added)")
+    ap.add_argument("--exact", action="store_true", help="lprob_kwargs exact_evidence=True: every weight and the ln-evidence in fp64")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -176,19 +181,25 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    kw = MODES[args.mode]
+    kw_cpu = MODES[args.mode]                               # what the oracle's logprob understands
+    kw = dict(kw_cpu, exact_evidence=True) if args.exact else dict(kw_cpu)
     M = args.nmodel
     strong = args.scaling == "strong" and world > 1
     sys.path.insert(0, ROOT)
     from frankenz_amd.sharded import shard_slice
-    if strong:
-        # the SAME problem on every rank count: one seed, objects [lo, hi) of the full set on this rank
-        N_total = args.nobj
-        sl = shard_slice(N_total, world, rank); lo, hi = sl.start, sl.stop
+    do_gather = world > 1 and not args.no_gather and args.workload == "fit_predict"
+    if world > 1 and (strong or do_gather):
+        # the SAME problem on every rank count: one seed; every rank holds the (small) full object arrays and the
+        # library deals the objects out (sharded_fit_predict).  Weak scaling: --nobj objects per rank.
+        N_total = args.nobj if strong else args.nobj * world
         Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N_total, M, 20260101, args.nband, args.noise_scale)
-        X, Xe, Xm = X[lo:hi], Xe[lo:hi], Xm[lo:hi]
-        N = hi - lo
-        n_pad = -(-N_total // world)                   # rows per rank in the gathered (world * n_pad, G) buffer
+        if do_gather:
+            N = N_total                                 # the rank's tensors hold every object; it computes its share
+        else:
+            sl = shard_slice(N_total, world, rank)
+            X, Xe, Xm = X[sl], Xe[sl], Xm[sl]
+            N = sl.stop - sl.start
+        n_pad = N
     else:
         N = args.nobj
         N_total = N * world
@@ -201,9 +212,9 @@ def main():
     # CPU baselines first: worker processes are spawned before this process initialises the GPU
     cpu1 = cpuall = None
     if world == 1 and not args.no_cpu and args.workload == "fit_predict" and not args.prior:
-        cpu1 = cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, args.cpu_seconds)
+        cpu1 = cpu_baseline(Y, Ye, Ym, X, Xe, Xm, z, ze, kw_cpu, args.cpu_seconds)
         if (os.cpu_count() or 1) > 1:
-            cpuall = cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, min(args.cpu_seconds, 10.0))
+            cpuall = cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw_cpu, min(args.cpu_seconds, 10.0))
     import torch
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -223,14 +234,14 @@ def main():
             dist.init_process_group(backend)
 
     from frankenz_amd import PDFDict
-    from frankenz_amd.engine import Engine, kde_opts, like_opts
+    from frankenz_amd.engine import get_engine, kde_opts, like_opts
 
     if args.mask_frac > 0:
         Xm[np.random.RandomState(5).rand(*Xm.shape) < args.mask_frac] = 0.0
     pd = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
     G = pd.Ngrid
 
-    eng = Engine(local)
+    eng = get_engine(local)                                 # the process-wide engine of this GPU (the drop-in classes use the same one)
     eng.upload_models(Y, Ye, Ym)
     if args.kde == "grid":
         eng.set_labels(z, ze, label_grid=np.ascontiguousarray(pd.grid, dtype=np.float64))
@@ -238,13 +249,17 @@ def main():
         eng.set_labels(z, ze, label_dict=pd)
     dev = torch.device("cuda", local)
     dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
-    d_pdf = torch.zeros((n_pad, G), dtype=torch.float64, device=dev)         # n_pad >= N rows: equal shards for the all-gather
+    d_pdf = None if do_gather else torch.zeros((n_pad, G), dtype=torch.float64, device=dev)   # (N > 1: the sharded call owns the result)
     d_lm = torch.empty(N, dtype=torch.float64, device=dev)
     d_le = torch.empty(N, dtype=torch.float64, device=dev)
     gathered = None
-    do_gather = world > 1 and not args.no_gather and args.workload == "fit_predict"
+    bf = None
     if do_gather:
-        gathered = torch.empty((world * n_pad, G), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        # the library's multi-GPU call (drop-in class + sharded driver); the engine above is the same process-wide one
+        from frankenz_amd import BruteForce, sharded
+        os.environ["FRANKENZ_DEVICE"] = str(local)
+        bf = BruteForce(Y, Ye, Ym, device=local)
+        d_pdf = None                                             # the sharded call owns the (N, G) result
     opts, ko = like_opts(kw), kde_opts({"wt_thresh": args.wt_thresh})
     prior = None
     if args.prior > 0:
@@ -292,21 +307,21 @@ def main():
             eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
             eng.knn_fit_predict(dX, dXe, dXm, d_idx, Kt * kk, opts, ko, pdfs=d_pdf, lmap=d_lm, levid=d_le, n=N)
             return
+        if bf is not None:
+            # N > 1: shard compute + the overlapped RCCL all-gather of the PDF rows, as one library call
+            res = sharded.sharded_fit_predict(bf, dX, dXe, dXm, z, ze, gather='pdfs', chunks=args.chunks, label_dict=pd if args.kde == "dict" else None,
+                                              label_grid=None if args.kde == "dict" else np.ascontiguousarray(pd.grid, dtype=np.float64),
+                                              lprob_kwargs=kw, kde_kwargs={"wt_thresh": args.wt_thresh}, save_fits=False)
+            last[0] = res
+            st = sharded.last_stats
+            split[0] += st["ms_compute"] * 1e-3; split[1] += st["ms_gather_exposed"] * 1e-3
+            return
         t0 = time.perf_counter()
         eng.fit_predict_prior(dX, dXe, dXm, opts, ko, prior, d_pdf, d_lm, d_le, n=N)       # returns when the PDFs are in HBM
-        t1 = time.perf_counter()
-        if gathered is not None:
-            # RCCL all-gather of the stacked PDFs (north_star).  The step ends only when the collective has
-            # finished: the next step's kernel writes the same shard buffer.
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, d_pdf)
-                torch.cuda.synchronize()
-            else:                                            # plumbing run on a GPU-less / 1-GPU box: gloo over host memory
-                dist.all_gather_into_tensor(gathered, d_pdf.cpu())
-        t2 = time.perf_counter()
-        split[0] += t1 - t0; split[1] += t2 - t1
+        split[0] += time.perf_counter() - t0
 
-    split = [0.0, 0.0]              # seconds in compute / in the all-gather over the timed steps
+    split = [0.0, 0.0]              # seconds in compute / in the exposed part of the all-gather over the timed steps
+    last = [None]                   # N > 1: the last step's gathered (pdfs, (lmap, levid))
 
     def fence():
         eng.sync()
@@ -334,7 +349,13 @@ def main():
 
     # sanity: PDFs are normalised
     ok = True
-    if args.workload != "fit":
+    if bf is not None:
+        d_pdf = last[0][0]
+        N_chk = int(d_pdf.shape[0])
+        assert N_chk == N_total
+        s = d_pdf[:: max(1, N_chk // 4096)].sum(dim=1)           # rows of every rank's share
+        ok = bool(torch.isfinite(s).all().item()) and float((s - 1).abs().max().item()) < 1e-9
+    elif args.workload != "fit":
         s = d_pdf[: min(N, 4096)].sum(dim=1)
         ok = bool(torch.isfinite(s).all().item()) and float((s - 1).abs().max().item()) < 1e-9
     if args.workload != "fit_predict" and rank == 0:
@@ -370,7 +391,8 @@ def main():
                               "pdfs_normalised": ok, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "BruteForce.predict(logwt=fit_lnprob): %d x %d plane -> %d PDFs" % (N, M, N)},
                               "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in ("fused", "stats", "kde", "other")},
-                              "roofline": {"bound": "hbm", "kernel": "k_stats + k_kde", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                              "roofline": {"bound": "hbm", "kernel": "k_plane_fused" if tm["ms_fused"] > tm["ms_stats"] + tm["ms_kde"] else "k_stats + k_kde",
+                                           "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                            "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))
         else:
@@ -385,70 +407,82 @@ def main():
     if rank == 0 and args.workload == "fit_predict":
         evals = float(N_total) * M * args.steps
         value = evals / dt
+        n_local = (N_total / world) if do_gather else N         # objects this rank's kernels processed per step
         # dominant kernel, HIP events on the library's own stream (per launch)
         fam = max(("fused", "stats", "kde", "modec"), key=lambda k: tm["ms_" + k])
         ms_launch = tm["ms_" + fam] / max(tm["n_" + fam], 1)
         launches_per_step = max(tm["n_" + fam], 1) / args.steps
-        evals_per_launch = N * M / launches_per_step
+        evals_per_launch = n_local * M / launches_per_step
         flops_eval = flops_per_eval(args.mode, args.nband, fam == "fused") if fam != "modec" else None
         ach = evals_per_launch * flops_eval / (ms_launch * 1e-3) / 1e12 if flops_eval else None
-        traffic = None
+        form = eng.last_form() if fam == "fused" else {"stats": "k_stats + k_kde", "kde": "k_stats + k_kde", "modec": "k_modec_step"}[fam]
+        # HBM traffic: PMC passes of THIS build at THIS launch shape, kept in profiles/pmc_latest.json by tools/pmc.sh
+        # (rocprofv3 cannot run inside the bench); only a matching (kernel form, objects per launch) entry is reported
+        traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
             try:
-                per_eval = json.load(open(prof)).get("k_" + fam, {}).get("hbm_bytes_per_eval")
-                traffic = per_eval * evals_per_launch if per_eval else None     # PMC pass of profiles/, scaled to this launch
+                for ent in json.load(open(prof)).get("entries", []):
+                    if ent.get("form") == form and ent.get("mode") == args.mode and ent.get("model_err") == args.model_err \
+                            and abs(ent.get("evals_per_launch", 0) - evals_per_launch) <= 0.01 * evals_per_launch:
+                        traffic = ent["hbm_bytes_per_launch"]; traffic_src = ent.get("source")
             except Exception:
                 traffic = None
+        is_cfg2 = (N_total == 1000000 and M == 100000 and args.nband == 5)
+        what = ("BASELINE configs[2]: " if is_cfg2 else "") + "%d objects x %d models x %d bands%s" % (
+            N_total, M, args.nband, (" sharded over %d GPUs (object axis, block-cyclic rounds)" % world) if world > 1 else "")
+        kde_txt = ("gauss_kde_dict on the 701-pt grid (500-kernel dictionary" + (", per-model label errors" if args.label_err == "varying" else "") + ")") \
+            if args.kde == "dict" else "direct gauss_kde on the 701-pt grid"
+        exact = bool(kw.get("exact_evidence")) or bool(os.environ.get("FZ_EXACT_EVIDENCE"))
         out = {
             "metric": "object-template likelihood evals/sec (fused fit_predict -> PDFs)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
-            "dtype": "f64 (chi2, ln-likes, weights and PDFs of every model within wt_thresh of the best; the sum of the "
-                     "remaining sub-threshold weights in the ln-evidence runs in fp32: DESIGN.md 3.1)",
+            "dtype": ("f64 throughout (chi2, ln-likes, every weight, ln-evidence, PDFs)" if exact or "exact" in form else
+                      "f64 (chi2, ln-likes, PDFs and the weight of every model within wt_thresh of the best); the sum of the "
+                      "remaining sub-threshold weights in the ln-evidence runs in fp32 (DESIGN.md 3.1; roofline_fp64 is the "
+                      "all-fp64 form, lprob_kwargs={'exact_evidence': True})"),
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d objects x %d models x %d bands%s, "
-                                   "BruteForce.fit_predict(save_fits=False), likelihood mode %s, "
-                                   "dict KDE on 701-pt grid" % (N_total, M, args.nband,
-                                                               (" sharded over %d GPUs (object axis, contiguous blocks)" % world)
-                                                               if world > 1 else "", args.mode),
-                       "n_obj_total": N_total, "n_obj_per_gpu": N, "n_model": M, "n_band": args.nband, "mode": args.mode,
-                       "lprob_kwargs": kw, "gather_pdfs": bool(gathered is not None),
+            "config": {"workload": "%s, BruteForce.fit_predict(save_fits=False), likelihood mode %s%s, %s" % (
+                           what, args.mode, " (per-model errors)" if args.model_err == "varying" else "", kde_txt),
+                       "kernel_form": form,
+                       "n_obj_total": N_total, "n_obj_per_gpu": n_local, "n_model": M, "n_band": args.nband, "mode": args.mode,
+                       "lprob_kwargs": kw, "gather_pdfs": bool(do_gather),
                        "mask_frac": args.mask_frac, "prior_rows": args.prior, "model_err": args.model_err,
                        "noise_scale": args.noise_scale, "kde": args.kde, "label_err": args.label_err},
             "note": ("band-constant model errors (the SURVEY 8d configuration): xe^2 + ye^2 is formed once per object "
-                     "and mode A runs on the mode-Ai kernels; --model-err varying times the general mode A kernels"
+                     "and mode A runs on the mode-Ai kernels; roofline_general (--model-err varying) times the general mode A kernels"
                      if (args.model_err == "const" and args.mode in ("A", "An")) else None),
             "pdfs_per_s": float(N_total) * args.steps / dt,
-            "ms_compute": split[0] / args.steps * 1e3, "ms_gather": split[1] / args.steps * 1e3,
-            "gather": ({"collective": "all_gather_into_tensor (RCCL)" if backend == "nccl" else "all_gather (gloo, host)",
-                        "bytes_per_rank": n_pad * G * 8, "bytes_total": world * n_pad * G * 8,
-                        "algbw_GBs": (world * n_pad * G * 8 / (split[1] / args.steps) / 1e9) if split[1] > 0 else None,
-                        "busbw_GBs": (world * n_pad * G * 8 * (world - 1) / world / (split[1] / args.steps) / 1e9) if split[1] > 0 else None}
-                       if gathered is not None else None),
+            "ms_compute": split[0] / args.steps * 1e3,
+            "ms_gather_exposed": (split[1] / args.steps * 1e3) if do_gather else None,
+            "gather": ({"collective": ("in-place all_gather_into_tensor per round (RCCL, async_op, overlapped with the next round's kernel)"
+                                       if backend == "nccl" else "all_gather per round (gloo through host memory: plumbing only)"),
+                        "library_call": "frankenz_amd.sharded.sharded_fit_predict", "rounds": sharded.last_stats.get("chunks"),
+                        "bytes_total": N_total * G * 8, "bytes_received_per_rank": N_total * G * 8 * (world - 1) / world,
+                        "ms_total_per_step": sharded.last_stats.get("ms_total"),
+                        "busbw_GBs_if_fully_exposed": (N_total * G * 8 * (world - 1) / world / (split[1] / args.steps) / 1e9) if split[1] > 0 else None}
+                       if do_gather else None),
             "pdfs_normalised": ok,
             "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in
                                    ("fused", "stats", "kde", "planes", "modec", "other")},
-            "roofline": {"bound": "mfma", "pipe": "valu_fp64 (the fp64 vector rate equals the dense fp64 MFMA peak on gfx950; "
-                                                   "the kernel is compute-bound on the vector ALU, see DESIGN.md 3.6)",
-                         "kernel": "k_" + fam, "achieved": ach,
+            "roofline": {"bound": "valu", "pipe": "fp64 vector ALU (its rate equals the dense fp64 MFMA peak on gfx950; no MFMA in this kernel: "
+                                                   "K = 5 contractions, DESIGN.md 3.6)",
+                         "kernel": form, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of this build), "
-                                           "scaled to this launch; not collected in this run",
+                         "traffic_source": traffic_src or "no PMC entry for this kernel form and launch shape in profiles/pmc_latest.json",
                          "flops_per_eval": flops_eval,
-                         "avg_launch_ms": ms_launch,
-                         "fused_frac": (N * M * args.steps * flops_per_eval(args.mode, args.nband)
-                                        / ((tm["ms_fused"] + tm["ms_stats"] + tm["ms_kde"]) * 1e-3) / 1e12
-                                        / FP64_VALU_PEAK_TFLOPS) if flops_per_eval(args.mode, args.nband) else None,
+                         "avg_launch_ms": ms_launch, "evals_per_launch": evals_per_launch,
                          "modec_iterations_per_step": (tm["n_modec"] / args.steps - 2) if fam == "modec" else None},   # minus the two timed scopes (iteration driver, final pass)
         }
         if world == 1 and args.mode == "A" and args.model_err == "const" and not args.prior and args.mask_frac == 0 \
-                and args.kde == "dict" and args.label_err == "const" and args.noise_scale == 1.0 and not os.environ.get("FZ_BENCH_NO_EXTRA"):
-            # the headline configuration has band-constant model errors (the easy case of mode A): the same
-            # workload on the GENERAL mode A kernels (per-model errors) and with the free scale (mode B), two
-            # steps each, so that the driver's record does not only hold the hoisted case
+                and args.kde == "dict" and args.label_err == "const" and args.noise_scale == 1.0 and not exact \
+                and not os.environ.get("FZ_BENCH_NO_EXTRA"):
+            # the headline configuration has band-constant model errors (the easy case of mode A) and an fp32 remainder in the
+            # evidence: the same workload (a) all-fp64, (b) on the GENERAL mode A kernels (per-model errors) and (c) with the free
+            # scale (mode B), two steps each, so that the driver's record holds the cases real data run on
             def extra(Ye2, kw2, mode2):
                 eng.upload_models(Y, Ye2, Ym)
                 eng.set_labels(z, ze, label_dict=pd)               # labels belong to the model set they were uploaded with
@@ -465,7 +499,9 @@ def main():
                 fl = flops_per_eval(mode2, args.nband)
                 a2 = N * M / (max(tm2["n_fused"], 1) / 2) * fl / (ms2 * 1e-3) / 1e12
                 return {"value": N * M / dt2, "unit": "evals/s", "ms_per_step": dt2 * 1e3, "achieved": a2, "peak": FP64_VALU_PEAK_TFLOPS,
-                        "frac": a2 / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": fl, "avg_launch_ms": ms2}
+                        "frac": a2 / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": fl, "avg_launch_ms": ms2, "kernel": eng.last_form()}
+            out["roofline_fp64"] = dict(extra(Ye, {"exact_evidence": True}, "A"),
+                                        note="the headline workload with every weight and the whole ln-evidence in fp64 (lprob_kwargs={'exact_evidence': True})")
             out["roofline_general"] = dict(extra(Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape), {}, "A"),
                                            note="mode A with per-model errors (--model-err varying): the general kernels")
             out["roofline_modeB"] = dict(extra(Ye, MODES["B"], "B"), note="free scale, model errors ignored (--mode B)")

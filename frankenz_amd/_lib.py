@@ -47,6 +47,7 @@ ABI = {
     "fz_sync": (C.c_int, [_P]),
     "fz_timing_reset": (C.c_int, [_P]),
     "fz_timing_get": (C.c_int, [_P, C.POINTER(Timing)]),
+    "fz_last_form": (C.c_char_p, [_P]),
     "fz_set_workspace_limit": (C.c_int, [_P, _I64]),
     "fz_models_upload": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
     "fz_kdedict_upload": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),

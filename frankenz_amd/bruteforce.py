@@ -76,6 +76,58 @@ def _progress(verbose, what, i, n):
         sys.stderr.flush()
 
 
+class _Prepared(object):
+    """A model set + labels resident on the device and the option structs of one ``fit_predict`` configuration
+    (``BruteForce.prepare_fit_predict``)."""
+
+    def __init__(self, bf, eng, opts, ko, Nx, prior):
+        self.bf, self.eng, self.opts, self.ko, self.Nx, self.prior = bf, eng, opts, ko, Nx, prior
+
+    def run(self, data, data_err, data_mask, out=None, save_fits=False, track_scale=False):
+        """-> (pdfs, lmap, levid): ``out`` if given (float64, C-contiguous, NumPy or tensors on the engine's GPU), else fresh
+        arrays of the kind ``data`` is.  Device tensors are cleaned in place by the library (pdf.py:310-311)."""
+        bf, eng, Nx = self.bf, self.eng, self.Nx
+        on_dev = hasattr(data, "data_ptr")
+        Ndata = int(data.shape[0])
+        bf._ndata_all = Ndata
+        if out is None:
+            if on_dev:
+                import torch
+                out = (torch.empty((Ndata, Nx), dtype=torch.float64, device=data.device),
+                       torch.empty(Ndata, dtype=torch.float64, device=data.device),
+                       torch.empty(Ndata, dtype=torch.float64, device=data.device))
+            else:
+                out = (np.zeros((Ndata, Nx)), np.zeros(Ndata), np.zeros(Ndata))
+        pdfs, lmap, levid = out
+        for a, shp in ((pdfs, (Ndata, Nx)), (lmap, (Ndata,)), (levid, (Ndata,))):
+            if tuple(a.shape) != shp or str(a.dtype).split('.')[-1] != 'float64':
+                raise ValueError("`out` must hold float64 arrays of shape (Ndata, Nx), (Ndata,), (Ndata,); got %s %s"
+                                 % (tuple(a.shape), a.dtype))
+            if (hasattr(a, "is_contiguous") and not a.is_contiguous()) or (isinstance(a, np.ndarray) and not a.flags.c_contiguous):
+                raise ValueError("`out` arrays must be C-contiguous")
+        if on_dev:
+            for a in (data, data_err, data_mask):
+                if tuple(a.shape) != tuple(data.shape) or not a.is_contiguous() or str(a.dtype) != 'torch.float64':
+                    raise ValueError("device objects must be contiguous float64 tensors of one (Ndata, Nfilt) shape")
+            x, xe, xm, obj = data, data_err, data_mask, None
+        else:
+            obj = HostObjects(data, data_err, data_mask)
+            x, xe, xm = obj.x, obj.xe, obj.xm
+            if save_fits:
+                bf.NDATA = Ndata
+                bf._alloc_fits(Ndata)
+                step = max(1, min(Ndata, (1 << 28) // max(bf.NMODEL, 1)))
+                for lo in range(0, Ndata, step):
+                    bf._fit_block(eng, obj, lo, min(Ndata, lo + step), self.opts, track_scale, self.prior)
+        if Ndata:
+            eng.fit_predict_prior(x, xe, xm, self.opts, self.ko,
+                                  self.prior.chunk(0, Ndata, Ndata) if self.prior is not None else None,
+                                  pdfs, lmap, levid, n=Ndata)
+        if obj is not None:
+            obj.writeback()
+        return pdfs, lmap, levid
+
+
 class BruteForce():
     """Fits data and generates predictions using a brute-force search over all
     models (bruteforce.py:30-34)."""
@@ -298,10 +350,25 @@ class BruteForce():
     def fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs,
                     lprob_func=None, label_dict=None, label_grid=None, kde_args=None,
                     kde_kwargs=None, lprob_args=None, lprob_kwargs=None, return_gof=False,
-                    track_scale=False, verbose=True, save_fits=True):
+                    track_scale=False, verbose=True, save_fits=True, out=None):
         """bruteforce.py:374-503.  ``save_fits=False`` is the streaming path that never
-        materialises (Ndata, Nmodel); ``save_fits=True`` additionally fills ``fit_*``."""
+        materialises (Ndata, Nmodel); ``save_fits=True`` additionally fills ``fit_*``.
+
+        Extension (no reference counterpart): ``out=(pdfs, lmap, levid)`` -- caller-allocated float64 arrays of
+        shape (Ndata, Nx), (Ndata,), (Ndata,), NumPy or torch tensors on this engine's GPU -- receives the
+        results in place and is what the call returns; with device tensors for ``data`` / ``out`` nothing
+        crosses PCIe (the sharded driver gathers PDF shards straight out of such a buffer)."""
         prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
+        if out is not None or hasattr(data, "data_ptr"):
+            if host is not None or save_fits and hasattr(data, "data_ptr"):
+                raise NotImplementedError("device tensors / `out=` need the built-in likelihood and save_fits=False "
+                                          "(the fit_* planes are host arrays)")
+            if kde_args:
+                raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+            if label_dict is None and label_grid is None:
+                raise ValueError("`label_dict` or `label_grid` must be specified.")
+            return self._fit_predict_into(data, data_err, data_mask, model_labels, model_label_errs, label_dict, label_grid,
+                                          kde_kwargs, lprob_kwargs, prior, return_gof, track_scale, save_fits, out)
         if kde_args:
             raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
         if label_dict is None and label_grid is None:
@@ -346,6 +413,27 @@ class BruteForce():
         if return_gof:
             return pdfs, (lmap, levid)
         return pdfs
+
+    def prepare_fit_predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, kde_kwargs=None,
+                            lprob_kwargs=None, prior=None):
+        """Extension: everything of ``fit_predict`` that does not depend on the objects -- model set, dictionary and labels
+        on the device, option structs -- done once; the returned ``run(data, data_err, data_mask, out)`` then only moves
+        objects.  A driver that feeds many blocks of objects through one model set (``sharded_fit_predict``'s rounds) pays
+        the uploads / content checks once instead of per block."""
+        if label_dict is None and label_grid is None:
+            raise ValueError("`label_dict` or `label_grid` must be specified.")
+        opts = like_opts(lprob_kwargs)
+        ko = kde_opts(kde_kwargs)
+        eng = self._engine()
+        Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
+        return _Prepared(self, eng, opts, ko, Nx, prior)
+
+    def _fit_predict_into(self, data, data_err, data_mask, model_labels, model_label_errs, label_dict, label_grid,
+                          kde_kwargs, lprob_kwargs, prior, return_gof, track_scale, save_fits, out):
+        """fit_predict with caller-owned outputs and / or device-resident objects (see ``fit_predict``)."""
+        prep = self.prepare_fit_predict(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs, lprob_kwargs, prior)
+        pdfs, lmap, levid = prep.run(data, data_err, data_mask, out, save_fits=save_fits, track_scale=track_scale)
+        return (pdfs, (lmap, levid)) if return_gof else pdfs
 
     def _fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs,
                      lprob_func=None, label_dict=None, label_grid=None, kde_args=None,

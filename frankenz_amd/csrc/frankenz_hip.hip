@@ -15,6 +15,7 @@ using namespace fz;
 
 std::string& fz_err_slot() { static thread_local std::string e; return e; }
 extern "C" const char* fz_last_error(void) { return fz_err_slot().c_str(); }
+extern "C" const char* fz_last_form(fz_ctx* c) { return c ? c->last_form.c_str() : ""; }
 
 extern "C" int fz_device_count(void) {
     int n = 0;
@@ -62,6 +63,8 @@ extern "C" void fz_ctx_destroy(fz_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_done[k]); (void)hipEventDestroy(c->ev_copied[k]); }
+    if (c->ev_probe) (void)hipEventDestroy(c->ev_probe);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -132,6 +135,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     const int BT = pick_bt(B);
     if (!BT) return fail(-5, "fz_models_upload: %d bands unsupported (max 32)", B);
     HIPCHK(hipSetDevice(c->device));
+    c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
     const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     const size_t raw = (size_t)M * B * sizeof(double);
     FZCHK(c->d_rx.ensure(raw)); FZCHK(c->d_rxe.ensure(raw)); FZCHK(c->d_rxm.ensure(raw));
@@ -207,6 +211,7 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     if (!c->D) return fail(-1, "fz_labels_upload_dict: upload the dictionary first");
     if (M <= 0) return fail(-1, "fz_labels_upload_dict: M <= 0");
     HIPCHK(hipSetDevice(c->device));
+    c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
     const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     std::vector<int64_t> hy(M), hs(M);
     if (is_device_ptr(y_idx)) {
@@ -341,6 +346,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (!c || !y || !ystd || !grid) return fail(-1, "fz_labels_upload_grid: NULL argument");
     if (M <= 0 || G <= 1) return fail(-1, "fz_labels_upload_grid: bad sizes");
     HIPCHK(hipSetDevice(c->device));
+    c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
     const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
     FZCHK(c->d_ly.ensure(Mp * 8)); FZCHK(c->d_lstd.ensure(Mp * 8)); FZCHK(c->d_grid.ensure(G * 8));
     FZCHK(c->d_lo.ensure(Mp * 4)); FZCHK(c->d_hi.ensure(Mp * 4)); FZCHK(c->d_norm.ensure(Mp * 8));

@@ -63,6 +63,10 @@ struct fz_ctx {
     int64_t ws_limit = (int64_t)32 << 30;
     int cu_count = 256;
     int force_twopass = 0;     // diagnostics: disable the single-pass fused kernel
+    // share of (object, model) pairs within the weight threshold, sampled per fused launch and read back one launch later
+    // (pinned host word + event: the choice of kernel form never waits for the device after the first launch of a model set)
+    unsigned long long* h_probe = nullptr; hipEvent_t ev_probe = nullptr; bool probe_pending = false; double probe_share = -1.0;
+    std::string last_form;     // which kernel form the last fused launch took (fz_last_form)
     int exact_evidence = 0;    // every weight of the fused path's ln-evidence in fp64 (fz_like_opts.exact_evidence of the call being served)
 
     // models (BruteForce.__init__)

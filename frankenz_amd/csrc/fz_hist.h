@@ -45,6 +45,9 @@ namespace fz {
 // exp(r) by the degree-5 Taylor polynomial (remainder 9e-21), 2^(n mod 256 / 256) from the table, 2^(n div 256) into the
 // exponent field.  Same error bound as exp_core (tests/test_hip_fastmath.py covers both).
 #define FZ_HEXP_K 256
+#ifndef FZ_HIST_MP
+#define FZ_HIST_MP 1             // 64-model groups per trip of the model loop
+#endif
 #ifndef FZ_HIST_REFRESH
 #define FZ_HIST_REFRESH 32     // steps between two updates of the candidate bar (and flushes of the fp32 partial sums)
 #endif
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         HistState<TW> hs;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
+            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = EXACT ? 0.0 : (double)INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
             hs.tthr[o] = -120.f; hs.pend[o] = 0; hs.namb[o] = 0;
         }
         hs.tick = 0; hs.next = 1;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         auto settle = [&](int o, bool act, double c2, int tag) {
             const double w = act ? hist_exactw<WP, !EXACT>(c2, tbx) : 0.0;
             hs.Sc[o] += w;
+
             const bool below = c2 <= K;
             hs.lo[o] = vmax_raw(hs.lo[o], (act && below) ? c2 : -INFINITY);
             hs.hi[o] = vmin_raw(hs.hi[o], (act && !below) ? c2 : INFINITY);
@@ -249,43 +253,59 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave);
             if (work) {
                 const int32_t* tags = reinterpret_cast<const int32_t*>(cur + TDR);
-                // the next step's record is requested before the current one is used
-                typename SRC::MR mn;
-                int tagn = 0;
-                src.template load_model_lds<TILE>(cur, lane, mn);
-                if (!SCRB) tagn = tags[lane];
+                // MP 64-model groups per trip: their chi2 chains and weights sit in one basic block (the appends, which
+                // branch, follow), and the next trip's records are requested before the current ones are used
+                constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
+                static_assert((TILE / 64) % MP == 0, "groups per trip must divide the tile");
+                typename SRC::MR mn[MP];
+                int tagn[MP];
 #pragma unroll
-                for (int st = 0; st < TILE / 64; ++st) {
-                    const int j = t * TILE + st * 64 + lane;
-                    const typename SRC::MR m = mn;
-                    int ptag = tagn;
-                    asm volatile("" : "+v"(ptag));                // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
-                    if (st + 1 < TILE / 64) {
-                        src.template load_model_lds<TILE>(cur, (st + 1) * 64 + lane, mn);
-                        if (!SCRB) tagn = tags[(st + 1) * 64 + lane];
-                    }
-                    double c2[TW];
+                for (int q = 0; q < MP; ++q) {
+                    src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
+                    tagn[q] = SCRB ? 0 : tags[q * 64 + lane];
+                }
 #pragma unroll
-                    for (int o = 0; o < TW; ++o) {
-                        c2[o] = SCRB ? hist_screen_b<SRC>(ob[o], m, xiv[o], Aq[o]) : src.chi2_of(ob[o], m);
-                        if (TAIL) c2[o] = (j < M) ? c2[o] : 1e30;   // pad lanes: weight 0
+                for (int st = 0; st < TILE / 64; st += MP) {
+                    typename SRC::MR m[MP];
+                    int ptag[MP];
+#pragma unroll
+                    for (int q = 0; q < MP; ++q) {
+                        m[q] = mn[q]; ptag[q] = tagn[q];
+                        asm volatile("" : "+v"(ptag[q]));         // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
                     }
+                    if (st + MP < TILE / 64) {
+#pragma unroll
+                        for (int q = 0; q < MP; ++q) {
+                            src.template load_model_lds<TILE>(cur, (st + MP + q) * 64 + lane, mn[q]);
+                            if (!SCRB) tagn[q] = tags[(st + MP + q) * 64 + lane];
+                        }
+                    }
+                    double c2[MP][TW];
+#pragma unroll
+                    for (int q = 0; q < MP; ++q)
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            c2[q][o] = SCRB ? hist_screen_b<SRC>(ob[o], m[q], xiv[o], Aq[o]) : src.chi2_of(ob[o], m[q]);
+                            if (TAIL) c2[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? c2[q][o] : 1e30;   // pad lanes: weight 0
+                        }
                     if constexpr (EXACT) {
+                        const int j = t * TILE + st * 64 + lane;
 #pragma unroll
                         for (int o = 0; o < TW; ++o) {
                             // every pair in fp64; the running best (of the exact weights) bounds what can still be stacked
                             const bool valid = !TAIL || j < M;
-                            const double w = valid ? hist_exactw<WP, false>(c2[o], tbx) : 0.0;
+                            const double w = valid ? hist_exactw<WP, false>(c2[0][o], tbx) : 0.0;
                             hs.S[o] += w;
-                            const bool up = w > hs.Sc[o];           // (EXACT: Sc holds the lane's best weight so far, lo its chi2)
-                            hs.Sc[o] = up ? w : hs.Sc[o];
-                            hs.lo[o] = up ? c2[o] : hs.lo[o];
-                            if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag + w0], w);
+                            const bool up = w > hs.hi[o];           // (EXACT: hi holds the lane's best weight so far, lo its chi2; Sc the wave's bar)
+                            hs.hi[o] = up ? w : hs.hi[o];
+                            hs.lo[o] = up ? c2[0][o] : hs.lo[o];
+                            hs.Sc[o] = vmax_raw(hs.Sc[o], w);
+                            if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag[0] + w0], w);
                             const bool am = valid && !(w > thr_def) && (w >= wt_thresh * 0.999 * hs.Sc[o]);
                             const unsigned long long mask = __ballot(am);
                             if (mask) {
                                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                                if (am) { Cand e; e.lnl = c2[o]; e.j = ptag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                                if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                                 hs.namb[o] += __builtin_popcountll(mask);
                             }
                         }
@@ -294,47 +314,57 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             for (int o = 0; o < TW; ++o) hs.Sc[o] = wave_max(hs.Sc[o]);
                         }
                     } else {
-                        float tl[TW];
+                        float tl[MP][TW], w[MP][TW];
 #pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-                            const float cf = (float)c2[o];
-                            const float l2 = __builtin_amdgcn_logf(cf);                 // chi2 == 0: -inf; a negative screen value: nan
-                            const float df = (float)(c2[o] - K);                        // fp64 difference, then fp32
-                            const float tt = fmaf(l2, 0.5f * WP, fmaf(df, -0.72134752f, T0));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(tl[o]) : "v"(tt), "v"(-200.f));   // nan / -inf -> -200: no weight
-                        }
-#pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-                            const float w = __builtin_amdgcn_exp2f(tl[o]);
-                            const bool c = tl[o] > hs.tthr[o];
-                            asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[o]));
-                            hs.s[o] += c ? 0.f : w;
-                            // candidates -> the object's ring (ballot + mbcnt compaction); positions are wave-uniform scalars
-                            const unsigned long long mask = __ballot(c);
-                            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            const int slot = hs.pend[o] + pre;      // < 64 wait when a step begins, a step adds at most 64: never past CAP
-#if !defined(FZ_DIAG_NOAPPEND)
-                            if (c) { rc2[o * CAP + slot] = c2[o]; rtag[o * CAP + slot] = (tag_t)(SCRB ? j : ptag); }
-#endif
-                            hs.pend[o] += __builtin_popcountll(mask);
-                        }
-                        if (++hs.tick == hs.next) {                                   // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
-                            hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
+                        for (int q = 0; q < MP; ++q)
 #pragma unroll
                             for (int o = 0; o < TW; ++o) {
-                                hs.S[o] += (double)hs.s[o]; hs.s[o] = 0.f;
-                                const float mx = wave_maxf_dpp(hs.tmax[o]);
-                                hs.tmax[o] = mx;
-                                hs.tthr[o] = fmaxf(mx + lthr2, -120.f);
+                                const float cf = (float)c2[q][o];
+                                const float l2 = __builtin_amdgcn_logf(cf);             // chi2 == 0: -inf; a negative screen value: nan
+                                const float df = (float)(c2[q][o] - K);                 // fp64 difference, then fp32
+                                tl[q][o] = fmaf(l2, 0.5f * WP, fmaf(df, -0.72134752f, T0));   // -inf for chi2 == 0; nan only beyond fp32's range
                             }
-                        }
 #pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-#if defined(FZ_DIAG_NODRAIN)
-                            if (hs.pend[o] >= DTHR) { hs.pend[o] -= 64; }
-#else
-                            while (hs.pend[o] >= DTHR) drain(o);
+                        for (int q = 0; q < MP; ++q)
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) w[q][o] = __builtin_amdgcn_exp2f(tl[q][o]);
+#pragma unroll
+                        for (int q = 0; q < MP; ++q) {
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) {
+                                // ONE compare: at or below the bar -> the fp32 remainder; above it (or not a number: chi2 beyond fp32's
+                                // range, settled like any candidate and found weightless) -> the candidate buffer
+                                const bool le = tl[q][o] <= hs.tthr[o];
+                                const bool c = !le;
+                                asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[q][o]));   // (a nan operand yields the other one)
+                                hs.s[o] += le ? w[q][o] : 0.f;
+                                // candidates -> the object's buffer (ballot + mbcnt compaction); its fill level is a wave-uniform scalar
+                                const unsigned long long mask = __ballot(c);
+                                // (v_mbcnt adds its count to a base: the fill level)  < 64 wait when a group begins, a group adds at most 64: never past CAP
+                                const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, hs.pend[o]));
+#if !defined(FZ_DIAG_NOAPPEND)
+                                if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)(SCRB ? t * TILE + (st + q) * 64 + lane : ptag[q]); }
 #endif
+                                hs.pend[o] += __builtin_popcountll(mask);
+                            }
+                            if (++hs.tick == hs.next) {                               // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
+                                hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
+#pragma unroll
+                                for (int o = 0; o < TW; ++o) {
+                                    hs.S[o] += (double)hs.s[o]; hs.s[o] = 0.f;          // fp32 partial sums -> fp64
+                                    const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bar follows the wave-wide best weight seen
+                                    hs.tmax[o] = mx;
+                                    hs.tthr[o] = fmaxf(mx + lthr2, -120.f);
+                                }
+                            }
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) {
+#if defined(FZ_DIAG_NODRAIN)
+                                if (hs.pend[o] >= DTHR) { hs.pend[o] -= 64; }
+#else
+                                while (hs.pend[o] >= DTHR) drain(o);
+#endif
+                            }
                         }
                     }
                 }
@@ -361,12 +391,12 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 if constexpr (!EXACT) {
                     while (hs.pend[o] > 0) drain(o);
                 } else {
-                    wbest_run = wave_max(hs.Sc[o]);
+                    wbest_run = wave_max(hs.hi[o]);
                 }
                 double lbest;                                                  // exact ln-like of the best model
                 if constexpr (EXACT) {
                     // the lane that holds the wave-wide best weight names the best model's chi2
-                    const unsigned long long who = __ballot(hs.Sc[o] == wbest_run && wbest_run > 0.0);
+                    const unsigned long long who = __ballot(hs.hi[o] == wbest_run && wbest_run > 0.0);
                     const int src_lane = who ? __builtin_ctzll(who) : 0;
                     const double cb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hs.lo[o]), src_lane),
                                                        __builtin_amdgcn_readlane(__double2loint(hs.lo[o]), src_lane));

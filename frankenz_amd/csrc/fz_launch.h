@@ -246,21 +246,38 @@ int fz_launch_fused_tw(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     return fz_launch_fused_wm<SRC, TW, NW, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
 }
 
-// share of the launch's (object, model) pairs within the weight threshold, from a sample (fz_nolist.h); < 0: not applicable
+// share of the launch's (object, model) pairs within the weight threshold, from a sample (fz_nolist.h); < 0: not applicable.
+// The sample of THIS launch is queued and read back by the NEXT one (pinned word + event), so only the first launch after a
+// model upload waits for the device; consecutive chunks / steps of one data set have the same statistics.
 template <class SRC>
 double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko) {
     if constexpr (!fz_has_wspace<SRC>()) return -1.0;
     else {
-        if (!fz_use_wspace(src) || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return -1.0;
+        if (!src.lp.dim_prior || getenv("FZ_NO_WSPACE") || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return -1.0;
         const int S = 256;
+        const double denom = (double)S * (double)((M + 255) / 256) * 64.0;
+        if (!c->h_probe) {
+            if (hipHostMalloc((void**)&c->h_probe, 8) != hipSuccess) { (void)hipGetLastError(); c->h_probe = nullptr; return -1.0; }
+            if (hipEventCreateWithFlags(&c->ev_probe, hipEventDisableTiming) != hipSuccess) return -1.0;
+        }
+        if (c->probe_pending) {                                   // the previous launch's sample has long landed
+            if (hipEventSynchronize(c->ev_probe) != hipSuccess) return -1.0;
+            c->probe_share = (double)*c->h_probe / denom;
+            c->probe_pending = false;
+        }
         if (c->d_flags.ensure(64) != 0) return -1.0;
         if (hipMemsetAsync(c->d_flags.p, 0, 8, c->stream) != hipSuccess) return -1.0;
         hipLaunchKernelGGL((fz::k_nl_probe<SRC>), dim3(S / 4), dim3(256), 0, c->stream, src, n, (int)M, S, ko->wt_thresh, c->omap,
                            c->d_flags.as<unsigned long long>());
-        unsigned long long cnt = 0;
-        if (hipMemcpyAsync(&cnt, c->d_flags.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1.0;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
-        return (double)cnt / ((double)S * (double)((M + 255) / 256) * 64.0);
+        if (hipMemcpyAsync(c->h_probe, c->d_flags.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1.0;
+        if (hipEventRecord(c->ev_probe, c->stream) != hipSuccess) return -1.0;
+        c->probe_pending = true;
+        if (c->probe_share < 0.0) {                               // nothing known yet: this once, wait
+            if (hipEventSynchronize(c->ev_probe) != hipSuccess) return -1.0;
+            c->probe_share = (double)*c->h_probe / denom;
+            c->probe_pending = false;
+        }
+        return c->probe_share;
     }
 }
 
@@ -448,9 +465,20 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // FZ_EXACT_EVIDENCE=1 (or like_opts.exact_evidence) the all-fp64 form
         const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
         fz_exact_now() = exact;
+        double share = -2.0;                                     // not sampled yet
         if (!getenv("FZ_HIST") || atoi(getenv("FZ_HIST")) != 0) {
-            r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact);
-            if (r <= 0) return r;
+            // When most pairs are within the weight threshold (faint data: the reference's own mock sits at 41 %), screening
+            // them first is wasted work: the all-fp64 form, which weighs every pair directly, is the faster one from ~45 % on
+            // (bench.py --noise-scale 3 / 10: 53 % / 95 %).  FZ_NOLIST=1 / 0 forces / forbids the switch.
+            bool broad = false;
+            if (!exact) {
+                const char* e = getenv("FZ_NOLIST");
+                const int want = e ? atoi(e) : -1;
+                if (want < 0 && n >= 16384) { share = fz_nolist_probe<SRC>(c, src, kv, n, M, ko); broad = share > 0.45; }
+                else broad = want == 1;
+            }
+            r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact || broad);
+            if (r <= 0) { c->last_form = (exact || broad) ? (exact ? "k_hist<exact>" : "k_hist<exact> (broad likelihoods)") : "k_hist<screen>"; return r; }
         }
         // broad likelihoods run without candidate lists (fz_nolist.h: two passes over the models, nothing in HBM).  The
         // share of pairs within the weight threshold is measured on 256 sampled objects of the launch; FZ_NOLIST=1 / 0
@@ -458,10 +486,10 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         {
             const char* e = getenv("FZ_NOLIST");
             int want = e ? atoi(e) : -1;
-            if (want < 0 && n >= 16384) want = fz_nolist_probe<SRC>(c, src, kv, n, M, ko) > 0.22 ? 1 : 0;
+            if (want < 0 && n >= 16384) want = (share > -2.0 ? share : fz_nolist_probe<SRC>(c, src, kv, n, M, ko)) > 0.22 ? 1 : 0;
             if (want == 1) {
                 r = fz_launch_nolist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                if (r <= 0) return r;
+                if (r <= 0) { c->last_form = "k_nl_max + k_nl_main"; return r; }
             }
         }
         if constexpr (SRC::WPOW == 3 && SRC::NB == 5) {
@@ -499,8 +527,9 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             else if (tw == 1 && nw == 4) r = fz_launch_fused_tw<SRC, 1, 4>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else return fail(-1, "FZ_FUSED_CFG=%d,%d is not an instantiated configuration", tw, nw);
         }
-        if (r <= 0) return r;
+        if (r <= 0) { c->last_form = "k_fused"; return r; }
     }
+    c->last_form = "k_stats + k_kde";
     if (c->omap) return 2;          // an object subset: only the fused kernel takes one; the caller redoes the whole chunk
     FZCHK(fz_launch_stats(c, src, n, M, 0, lmap, levid));
     return fz_launch_kde(c, src, n, M, 0, lmap, levid, ko, pdfs);

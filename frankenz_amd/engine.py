@@ -49,6 +49,33 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+try:
+    import xxhash as _xx
+
+    def _hash_bytes(h, a):
+        h.update(memoryview(a).cast('B'))
+
+    def _new_hash():
+        return _xx.xxh3_128()
+except ImportError:                                   # pragma: no cover  (xxhash ships with the image)
+    import hashlib as _hl
+
+    def _hash_bytes(h, a):
+        h.update(memoryview(a).cast('B'))
+
+    def _new_hash():
+        return _hl.blake2b(digest_size=16)
+
+
+def _digest(*arrays):
+    """(shapes, 128-bit content hash) of C-contiguous arrays: the key under which an upload is remembered"""
+    h = _new_hash()
+    for a in arrays:
+        if a.size:
+            _hash_bytes(h, a)
+    return (tuple(a.shape for a in arrays), h.hexdigest())
+
+
 class Engine(object):
     """One device context.  Not thread-safe."""
 
@@ -59,6 +86,7 @@ class Engine(object):
         self.h = h
         self.device = int(device)
         self.M = self.B = 0
+        self._models_key = self._dict_key = self._labels_key = self._trees_key = None      # content keys of what the device holds
 
     def close(self):
         if getattr(self, "h", None):
@@ -72,12 +100,20 @@ class Engine(object):
             pass
 
     # -- uploads ----------------------------------------------------------
+    # What is already on the device is not sent again.  The reference holds REFERENCES to the caller's model
+    # arrays (bruteforce.py:54-56), so an in-place edit between two calls must be seen: the key is a hash of the
+    # bytes (xxh3: ~1 ms per 12 MB), not the arrays' identity.
     def upload_models(self, models, models_err, models_mask):
         y, ye, ym = _f64(models), _f64(models_err), _f64(models_mask)
         if y.ndim != 2 or ye.shape != y.shape or ym.shape != y.shape:
             raise ValueError("models, models_err, models_mask must share a (Nmodel, Nfilt) shape")
+        key = _digest(y, ye, ym)
+        if key == self._models_key:
+            return
+        self._models_key = self._labels_key = None              # labels belong to the model set they were uploaded with
         check(self.lib.fz_models_upload(self.h, ptr(y), ptr(ye), ptr(ym), y.shape[0], y.shape[1]))
         self.M, self.B = y.shape
+        self._models_key = key
 
     def upload_dict(self, pdfdict):
         lens = np.array([len(k) for k in pdfdict.sigma_dict], dtype=np.int64)
@@ -86,20 +122,35 @@ class Engine(object):
         kern = _f64(np.concatenate(pdfdict.sigma_dict))
         kcdf = _f64(np.concatenate(pdfdict.sigma_dict_cdf))
         widths = np.ascontiguousarray(pdfdict.sigma_width, dtype=np.int64)
+        key = (int(pdfdict.Ngrid),) + _digest(widths, offs, kern, kcdf)
+        if key == self._dict_key:
+            return
+        self._dict_key = self._labels_key = None
         check(self.lib.fz_kdedict_upload(self.h, int(pdfdict.Ngrid), len(lens), ptr(widths),
                                          ptr(offs), ptr(kern), ptr(kcdf)))
+        self._dict_key = key
 
     def upload_labels_dict(self, y_idx, y_std_idx):
         yi = np.ascontiguousarray(y_idx, dtype=np.int64)
         si = np.ascontiguousarray(y_std_idx, dtype=np.int64)
+        key = ("dict", self._dict_key, self._models_key) + _digest(yi, si)
+        if key == self._labels_key and self._dict_key is not None:
+            return
+        self._labels_key = None
         check(self.lib.fz_labels_upload_dict(self.h, ptr(yi), ptr(si), len(yi)))
+        self._labels_key = key
 
     def upload_labels_grid(self, y, y_std, grid, dx=None, sig_thresh=5.0):
         y, ys, g = _f64(y), _f64(y_std), _f64(grid)
         if dx is None:
             dx = g[1] - g[0]
+        key = ("grid", float(dx), float(sig_thresh), self._models_key) + _digest(y, ys, g)
+        if key == self._labels_key:
+            return
+        self._labels_key = None
         check(self.lib.fz_labels_upload_grid(self.h, ptr(y), ptr(ys), len(y), ptr(g), len(g),
                                              float(dx), float(sig_thresh)))
+        self._labels_key = key
 
     def set_labels(self, labels, label_errs, label_dict=None, label_grid=None, kde_kwargs=None):
         """bruteforce.py:598-599 / 361-369: dictionary path if a PDFDict is given,
@@ -156,10 +207,17 @@ class Engine(object):
                                         ptr(pdfs), ptr(lmap), ptr(levid)))
 
     # -- k-NN ------------------------------------------------------------
-    def knn_upload_trees(self, feats):
+    def knn_upload_trees(self, feats, key=None):
+        """``key``: the caller's content key of ``feats`` (``_digest``); an unchanged set is not sent (nor Morton-sorted) again"""
         f = np.ascontiguousarray(feats, dtype=np.float32)
         K, M, F = f.shape
+        if key is None:
+            key = _digest(f)
+        if key == self._trees_key:
+            return
+        self._trees_key = None
         check(self.lib.fz_knn_upload_trees(self.h, ptr(f), K, M, F))
+        self._trees_key = key
 
     def knn_query(self, q, k, distance_upper_bound, idx, n=None, lp_norm=2):
         n = len(q) if n is None else n
@@ -223,6 +281,10 @@ class Engine(object):
         t = Timing()
         check(self.lib.fz_timing_get(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def last_form(self):
+        """which kernel form the last fused fit_predict launch took (depends on the data)"""
+        return self.lib.fz_last_form(self.h).decode("ascii", "replace")
 
     def set_workspace_limit(self, nbytes):
         check(self.lib.fz_set_workspace_limit(self.h, int(nbytes)))

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import pdf as _pdf
 from .bruteforce import _check_lprob, _progress
-from .engine import HostObjects, get_engine, kde_opts, like_opts
+from .engine import HostObjects, _digest, get_engine, kde_opts, like_opts
 
 __all__ = ["NearestNeighbors"]
 
@@ -111,7 +111,10 @@ class NearestNeighbors():
     def _engine(self):
         eng = get_engine(self._device)
         eng.upload_models(self.models, self.models_err, self.models_mask)
-        eng.knn_upload_trees(np.stack([t.data for t in self.KDTrees]))
+        if getattr(self, "_feats", None) is None:                 # the K feature sets are fixed at construction (knn.py:158-188)
+            self._feats = np.ascontiguousarray(np.stack([t.data for t in self.KDTrees]), dtype=np.float32)
+            self._feats_key = _digest(self._feats)
+        eng.knn_upload_trees(self._feats, key=self._feats_key)
         return eng
 
     def _search_setup(self, k, eps, lp_norm, distance_upper_bound):

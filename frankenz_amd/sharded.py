@@ -8,7 +8,13 @@ PDF depend on that object and the (replicated, ~12 MB) model set alone
 the compute.  What can be exchanged afterwards:
 
   * ``gather='pdfs'``  : all-gather of the (N/P, Nx) PDF shards -> the full (N, Nx)
-                         array on every rank;
+                         array on every rank.  For BruteForce the gather is OVERLAPPED with the
+                         compute (``_overlapped``): a rank's objects are dealt out block-cyclically
+                         in ``chunks`` rounds, round c's PDFs are written by the kernel straight into
+                         their rows of the full device array and leave on RCCL's stream (in-place
+                         ``all_gather_into_tensor``, ``async_op``) while round c + 1 is computed; one
+                         fence at the end.  Nothing crosses PCIe except the final result when the
+                         caller handed in NumPy arrays;
   * ``gather='stack'`` : all-reduce(sum) of the Nx-vector stacked PDF  sum_i pdf_i
                          (the population n(z) estimate), 5.6 KB.
 
@@ -38,6 +44,14 @@ def _dist():
     if not (dist.is_available() and dist.is_initialized()):
         return None
     return dist
+
+
+def _gpu_ok():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
 
 
 def _device_for(dist, group):
@@ -87,8 +101,91 @@ def allreduce_sum(vec, group=None):
     return t.cpu().numpy() if was_numpy else t
 
 
+last_stats = {}        # timing of the last overlapped call on this rank (ms_compute, ms_total, ms_gather_exposed, bytes, ...)
+
+
+def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs):
+    """BruteForce.fit_predict over all ranks with the PDF all-gather hidden behind the compute.
+
+    Object i belongs to round c = i // (P cs) and rank r = (i // cs) % P (cs = ceil(N / (P chunks))): the rows a
+    round produces are one contiguous (P cs, Nx) slab of the result, rank r's part at offset r cs of it -- which is
+    exactly the in-place form of an all-gather, so the kernel's output buffer IS the collective's buffer.
+    (bruteforce.py:602-631: no cross-object state, any assignment of objects to ranks gives the same rows.)"""
+    import time
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nccl = dist.get_backend(group) == "nccl"
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")   # (cpu: the gloo tests' stand-in fitter)
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    was_numpy = isinstance(data, np.ndarray)
+    N = int(data.shape[0])
+    label_dict, label_grid = kwargs.get("label_dict"), kwargs.get("label_grid")
+    if label_dict is None and label_grid is None:
+        raise ValueError("`label_dict` or `label_grid` must be specified.")
+    G = int(label_dict.Ngrid) if label_dict is not None else len(label_grid)
+
+    def dv(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if isinstance(a, np.ndarray) else a
+        return t.to(dev).contiguous()
+    dX, dXe, dXm = dv(data), dv(data_err), dv(data_mask)
+    # the reference cleans every object in place (pdf.py:310-311); every rank holds the full object arrays, so every
+    # rank's copy ends up cleaned, as after the single-process call (N x B values: negligible)
+    sync()                                                      # the library reads the tensors on its own stream
+    if N:
+        fitter._engine().clean(dX, dXe, dXm)
+    C = max(1, int(chunks))
+    cs = max(1, -(-N // (world * C)))
+    C = -(-N // (world * cs))                                   # rounds that hold at least one object
+    rows = C * world * cs
+    pdfs = torch.empty((rows, G), dtype=torch.float64, device=dev)
+    lm = torch.empty(rows, dtype=torch.float64, device=dev)
+    le = torch.empty(rows, dtype=torch.float64, device=dev)
+    extra = set(kwargs) - {"label_dict", "label_grid", "kde_kwargs", "lprob_kwargs", "lprob_func", "lprob_args", "kde_args",
+                           "return_gof", "save_fits", "verbose", "track_scale"}
+    if extra or kwargs.get("kde_args") or kwargs.get("lprob_args"):
+        raise NotImplementedError("sharded_fit_predict (overlapped BruteForce path): unsupported arguments %s" % sorted(extra))
+    # models, dictionary, labels: on the device once, not once per round
+    prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
+                                      kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"))
+    works, t_comp = [], 0.0
+    sync()
+    t_start = time.perf_counter()
+    for c in range(C):
+        base = c * world * cs
+        lo = base + rank * cs
+        hi = min(lo + cs, N)
+        if hi > lo:
+            t0 = time.perf_counter()
+            prep.run(dX[lo:hi], dXe[lo:hi], dXm[lo:hi], out=(pdfs[lo:hi], lm[lo:hi], le[lo:hi]))
+            t_comp += time.perf_counter() - t0              # the call returns when the rows are in HBM
+        for buf in (pdfs, lm, le):
+            out_v, in_v = buf[base:base + world * cs], buf[lo:lo + cs]
+            if nccl:
+                works.append(dist.all_gather_into_tensor(out_v, in_v, group=group, async_op=True))
+            else:                                                # gloo (tests, several ranks on one GPU): through host memory
+                tmp = torch.empty(out_v.shape, dtype=out_v.dtype)
+                dist.all_gather_into_tensor(tmp, in_v.cpu(), group=group)
+                out_v.copy_(tmp)
+    for w in works:
+        w.wait()
+    sync()
+    t_total = time.perf_counter() - t_start
+    nbytes = rows * G * 8
+    last_stats.clear()
+    last_stats.update(ms_compute=t_comp * 1e3, ms_total=t_total * 1e3, ms_gather_exposed=(t_total - t_comp) * 1e3,
+                      chunks=C, rows_per_chunk=cs, bytes_gathered=nbytes, world=world,
+                      busbw_GBs_if_serial=None)
+    if was_numpy:
+        for src, dst in ((dX, data), (dXe, data_err), (dXm, data_mask)):
+            dst[...] = src.cpu().numpy()
+        return pdfs[:N].cpu().numpy(), (lm[:N].cpu().numpy(), le[:N].cpu().numpy())
+    return pdfs[:N], (lm[:N], le[:N])
+
+
 def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_label_errs, gather='pdfs',
-                        group=None, rstate=None, **kwargs):
+                        group=None, rstate=None, chunks=4, **kwargs):
     """``fitter.fit_predict`` (BruteForce or NearestNeighbors) on this rank's block of objects.
 
     Returns ``(pdfs, (lmap, levid))``: the FULL arrays when ``gather='pdfs'``; the local
@@ -100,6 +197,15 @@ def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_l
     world = dist.get_world_size(group) if dist is not None else 1
     rank = dist.get_rank(group) if dist is not None else 0
     n = len(data)
+    if (gather == 'pdfs' and dist is not None and world > 1 and not hasattr(fitter, 'KDTrees') and chunks
+            and kwargs.get('lprob_func') is None and not kwargs.get('save_fits', False)
+            and (_gpu_ok() or getattr(fitter, 'accepts_tensors', False))):
+        # BruteForce with the built-in likelihood: device-resident, the gather overlapped with the compute
+        # (pass save_fits=False; the fit_* planes would be host arrays of the local block)
+        return _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs)
+    if hasattr(data, "data_ptr"):
+        raise NotImplementedError("device tensors are taken by the overlapped BruteForce path only "
+                                  "(gather='pdfs', save_fits=False, built-in likelihood)")
     sl = shard_slice(n, world, rank)
     kwargs = dict(kwargs, return_gof=True)
     kwargs.setdefault('verbose', False)

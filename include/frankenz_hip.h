@@ -83,6 +83,10 @@ void fz_ctx_destroy(fz_ctx* ctx);
 int  fz_sync(fz_ctx* ctx);
 int  fz_timing_reset(fz_ctx* ctx);
 int  fz_timing_get(fz_ctx* ctx, fz_timing* out);
+/* which kernel form the last fused fit_predict launch took ("k_hist<screen>", "k_hist<exact>", "k_fused",
+ * "k_stats + k_kde", ...): the choice depends on the data (likelihood mode, masks, label errors, how broad the
+ * likelihoods are), and a measurement should say what it measured.  No reference counterpart. */
+const char* fz_last_form(fz_ctx* ctx);
 /* byte budget for internal work space (candidate lists of the single-pass kernel, (N x M)
  * planes of mode C, host staging); default 45 % of the device memory, allocated on demand. */
 int  fz_set_workspace_limit(fz_ctx* ctx, int64_t bytes);

@@ -27,8 +27,8 @@ def scenario(name):
         return mk, obs, err, np.ones_like(obs), g['tr_z'], np.full(len(g['tr_z']), 0.05), dict(label_dict=d, save_fits=False)
     rs = np.random.RandomState(2026)
     sig = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
-    if name == 'bf_big':
-        N, M = 40000, 3000
+    if name in ('bf_big', 'bf_ragged'):
+        N, M = (40000, 3000) if name == 'bf_big' else (100003, 2000)       # ragged: no rank count divides it
         Y = rs.lognormal(1., 1., size=(M, 5)); Ye = np.tile(sig, (M, 1)); Ym = np.ones((M, 5))
         X = Y[rs.choice(M, N)] + sig * rs.randn(N, 5); Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, 5))
         X[7, 2] = np.nan; Xm[11, 0] = 0

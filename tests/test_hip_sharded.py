@@ -42,7 +42,7 @@ def unsharded(name):
     return p, lm, le, Xc, Xmc
 
 
-@pytest.mark.parametrize('name,world', [('bf_big', 1), ('bf_big', 2), ('knn', 2)])
+@pytest.mark.parametrize('name,world', [('bf_big', 1), ('bf_big', 2), ('bf_ragged', 4), ('knn', 2)])
 def test_sharded_hip_matches_the_unsharded_call(name, world, tmp_path):
     """bruteforce.py:602-631 has no cross-object state: blocks of objects computed by different ranks and
     all-gathered equal the single call (same launch geometry per object block: bitwise for ln-max, rounding
@@ -54,6 +54,7 @@ def test_sharded_hip_matches_the_unsharded_call(name, world, tmp_path):
         np.testing.assert_allclose(out['pdfs'], p, rtol=1e-12, atol=1e-16, equal_nan=True)
         np.testing.assert_array_equal(out['lmap'], lm)
         np.testing.assert_allclose(out['levid'], le, equal_nan=True, **EVID)
+        assert out['pdfs'].shape == p.shape
         np.testing.assert_allclose(out['stack'], np.nansum(p, axis=0), rtol=1e-11, atol=1e-14)
         from frankenz_amd.sharded import shard_slice
         sl = shard_slice(len(p), world, r)

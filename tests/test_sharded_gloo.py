@@ -21,13 +21,41 @@ class OracleBF(object):
     def __init__(self, Y, Ye, Ym, kd):
         self.Y, self.Ye, self.Ym, self.kd = Y, Ye, Ym, kd
 
-    def fit_predict(self, x, xe, xm, z, ze, return_gof=True, verbose=False, **kw):
+    def fit_predict(self, x, xe, xm, z, ze, return_gof=True, verbose=False, out=None, **kw):
         import frankenz_oracle as fo
+        if out is not None:                       # the device-resident form of the product (tensors in, rows written in place)
+            x, xe, xm = x.numpy(), xe.numpy(), xm.numpy()
         p, lm, le = fo.bruteforce_fit_predict(x, xe, xm, self.Y, self.Ye, self.Ym, z, ze, label_dict=self.kd)
+        if out is not None:
+            import torch
+            out[0].copy_(torch.from_numpy(p)); out[1].copy_(torch.from_numpy(lm)); out[2].copy_(torch.from_numpy(le))
+            return out[0], (out[1], out[2])
         return p, (lm, le)
 
 
-def _worker(rank, world, port, n, q):
+class OracleBFTensors(OracleBF):
+    """... that also takes the overlapped path of sharded_fit_predict (block-cyclic rounds, in-place all-gather)"""
+    accepts_tensors = True
+
+    def prepare_fit_predict(self, z, ze, label_dict=None, **kw):
+        bf = self
+
+        class _P(object):
+            @staticmethod
+            def run(x, xe, xm, out=None):
+                return bf.fit_predict(x, xe, xm, z, ze, out=out)
+        return _P()
+
+    def _engine(self):
+        class _E(object):
+            @staticmethod
+            def clean(x, xe, xm):                 # pdf.py:309-311 on the tensors' memory
+                import frankenz_oracle as fo
+                fo.clean_object(x.numpy(), xe.numpy(), xm.numpy())      # element-wise: works on the whole (N, B) arrays
+        return _E()
+
+
+def _worker(rank, world, port, n, q, tensors=False, chunks=4):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import torch.distributed as dist
     import frankenz_oracle as fo
@@ -41,8 +69,12 @@ def _worker(rank, world, port, n, q):
     X[1, 2] = np.nan                                  # exercises the in-place clean on rank 0's block
     z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
     kd = fo.KernelDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
-    bf = OracleBF(Y, Ye, Ym, kd)
-    full, (lm, le) = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather='pdfs')
+    bf = (OracleBFTensors if tensors else OracleBF)(Y, Ye, Ym, kd)
+    Xc = X.copy()
+    full, (lm, le) = sharded.sharded_fit_predict(bf, Xc, Xe.copy(), Xm.copy(), z, ze, gather='pdfs', label_dict=kd, chunks=chunks,
+                                                 save_fits=False)
+    if tensors:
+        assert sharded.last_stats['world'] == world and np.isfinite(Xc).all()       # overlapped path taken; every rank's copy is cleaned
     stack, _ = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather='stack')
     local, _ = sharded.sharded_fit_predict(bf, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather=None)
     ref, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=kd)
@@ -54,13 +86,15 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n', [10, 11])      # even and ragged split
-def test_two_rank_gloo_shard_and_gather(n):
+@pytest.mark.parametrize('world,n,tensors,chunks', [(2, 10, False, 4), (2, 11, False, 4),      # even and ragged split
+                                                    (8, 11, False, 4),                          # more ranks than some blocks hold rows: the pad path of allgather_rows
+                                                    (2, 11, True, 4), (2, 37, True, 3), (8, 37, True, 2), (3, 2, True, 4)])   # overlapped, block-cyclic rounds
+def test_gloo_shard_and_gather(world, n, tensors, chunks):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, tensors, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
