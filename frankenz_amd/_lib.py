@@ -18,7 +18,8 @@ class LikeOpts(C.Structure):
 
 class KdeOpts(C.Structure):
     _fields_ = [("wt_thresh", C.c_double), ("use_wt_thresh", C.c_int32),
-                ("normalize", C.c_int32), ("cdf_thresh", C.c_double)]
+                ("normalize", C.c_int32), ("cdf_thresh", C.c_double),
+                ("exact_evidence", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Prior(C.Structure):

@@ -734,7 +734,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M, G = c->G;
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
-    c->exact_evidence = o->exact_evidence != 0;
+    c->exact_evidence = (o->exact_evidence != 0) || (ko->exact_evidence != 0);
     const bool pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
     const bool cdf = !ko->use_wt_thresh;          // reference CDF rule: materialise the chunk's ln-like rows
     PriorBind pb; PriorGuard guard{c};
@@ -867,6 +867,7 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
     FZCHK(wait_for_producers(c, {logwt}));
+    c->exact_evidence = ko->exact_evidence != 0;
     const int64_t M = c->label_M, G = c->G;
     const bool in_dev = is_device_ptr(logwt), pdf_dev = is_device_ptr(pdfs), lm_dev = is_device_ptr(lmap), le_dev = is_device_ptr(levid);
     const int linear = is_log ? 0 : 1;

@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused(SRC src_, const KdeView* __re
 template <int VEC>
 struct PlaneState {
     double ref, s, m;          // wave-uniform reference; per-lane sum of exp(l - ref) and best l
+    float s32;                 // X32: the lane's fp32 partial sum of the non-candidates since the last flush into s
     bool anynan;
     int cnt;
 };
@@ -1201,7 +1202,12 @@ __device__ __forceinline__ void plane_load(const double* r, int jb, int M, int l
         }
     }
 }
-template <int VEC, int U, bool TAIL>
+// X32: the weight of an entry that cannot be stacked -- below wt_thresh of the best seen so far -- is formed and summed in
+// fp32 (difference l - ref in fp64 first, then one v_exp_f32: 5 instructions instead of the 14 of the fp64 exp); the
+// candidates' weights are left to the list walk, which forms them in fp64.  What reaches lmap, the PDFs and the stacked
+// weights is fp64 either way; the ln-evidence carries the fp32 remainder (~1e-9), as in the fused kernels.  X32 = false
+// (kde_opts.exact_evidence): every weight in fp64.
+template <int VEC, int U, bool TAIL, bool X32>
 __device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, int M, int lane, double lt,
                                            const FastTabs& tb, Cand* buf, PlaneState<VEC>& ps) {
     double mm = ps.m;
@@ -1209,8 +1215,9 @@ __device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, in
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int q = 0; q < VEC; ++q) { mm = vmax_raw(mm, l[u][q]); ps.anynan |= (l[u][q] != l[u][q]); }   // nan never becomes the best
-    if (__any(mm - ps.ref > 500.0)) {        // rare (first trip; the best jumps by > 500): re-base on the wave-wide best
+    if (__any(mm - ps.ref > (X32 ? 40.0 : 500.0))) {   // rare (first trip; the best jumps): re-base on the wave-wide best
         const double nr = wave_max(mm);
+        if (X32) { ps.s += (double)ps.s32; ps.s32 = 0.f; }
         ps.s *= exp_neg(ps.ref - nr, tb);    // ref = -inf: s is still 0
         ps.ref = nr;
     }
@@ -1220,10 +1227,18 @@ __device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, in
         for (int q = 0; q < VEC; ++q) {
             const int j = jb + (u * 64 + lane) * VEC + q;
             const double lv = l[u][q];
-            ps.s += exp_clamped(lv - ps.ref, tb);                     // nan, -inf and far tails -> ~1e-304
             ps.m = vmax_raw(ps.m, lv);
             bool c = lv >= ps.m + lt;                                 // >=: lt may be absorbed at huge |lnl|; false for nan
             if (TAIL) c = c && (j < M);
+            if (X32) {
+                // fp64 difference, then fp32: exp2((l - ref) log2 e); nan -> 0 (nans are flagged above), -inf -> 0
+                float t = (float)(lv - ps.ref) * 1.4426950408889634f;
+                asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(-150.f));
+                const float w = __builtin_amdgcn_exp2f(t);
+                ps.s32 += c ? 0.f : w;                                // the candidates are summed exactly by the list walk
+            } else {
+                ps.s += exp_clamped(lv - ps.ref, tb);                 // nan, -inf and far tails -> ~1e-304
+            }
             const unsigned long long mask = __ballot(c);
             if (mask) {                                               // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
@@ -1233,9 +1248,10 @@ __device__ __forceinline__ void plane_trip(const double (&l)[U][VEC], int jb, in
             }
         }
     }
+    if (X32) { ps.s += (double)ps.s32; ps.s32 = 0.f; }               // U * VEC terms per flush
 }
 
-template <int NW, int VEC, bool HO>
+template <int NW, int VEC, bool HO, bool X32>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plane_fused(const double* __restrict__ plane, int64_t ld,
                                                           const KdeView* __restrict__ kvp, int acc_stride, int64_t N,
                                                           int M, double wt_thresh, int normalize,
@@ -1258,7 +1274,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     for (int64_t i = gw; i < N; i += nwaves) {
         const double* r = plane + i * ld;
         PlaneState<VEC> ps;
-        ps.ref = -INFINITY; ps.s = 0.0; ps.m = -INFINITY; ps.anynan = false; ps.cnt = 0;
+        ps.ref = -INFINITY; ps.s = 0.0; ps.m = -INFINITY; ps.anynan = false; ps.cnt = 0; ps.s32 = 0.f;
         double l[U][VEC], ln[U][VEC];
         if (STEP <= M) plane_load<VEC, U, false>(r, 0, M, lane, l); else plane_load<VEC, U, true>(r, 0, M, lane, l);
         const bool firstnan = (lane == 0) && (l[0][0] != l[0][0]);
@@ -1267,8 +1283,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const int jn = jb + STEP;
             if (jn + STEP <= M) plane_load<VEC, U, false>(r, jn, M, lane, ln);
             else if (jn < M) plane_load<VEC, U, true>(r, jn, M, lane, ln);
-            if (jn <= M) plane_trip<VEC, U, false>(l, jb, M, lane, lt, tb, buf, ps);
-            else plane_trip<VEC, U, true>(l, jb, M, lane, lt, tb, buf, ps);
+            if (jn <= M) plane_trip<VEC, U, false, X32>(l, jb, M, lane, lt, tb, buf, ps);
+            else plane_trip<VEC, U, true, X32>(l, jb, M, lane, lt, tb, buf, ps);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1283,11 +1299,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const double ss = wave_sum(ps.s);
         const bool fn = __any(firstnan), an = __any(anynan);
         const double lm = fn ? (double)NAN : mx;                       // builtin max: NaN only if first
-        const double le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : ps.ref + log(ss));
-        if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
         // the entries were written by other lanes of this wave: stores drained, vector L1 invalidated
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double sx = ss;
+        if (X32) {                                                     // + the candidates' exact weights (a first, short walk)
+            double sc = 0.0;
+            const int n0 = __builtin_amdgcn_readfirstlane(cnt);
+            for (int c0 = lane; c0 < n0; c0 += 64) sc += exp_clamped(buf[c0].lnl - ps.ref, tb);
+            sx += wave_sum(sc);
+        }
+        const double le = an ? (double)NAN : (mx == INFINITY ? (double)INFINITY : ps.ref + log(sx));
+        if (lane == 0) { if (lmap) lmap[i] = lm; if (levid) levid[i] = le; }
         const bool ok = (le - le == 0.0);                              // finite evidence
         if (ok) {
             for (int k = lane; k < acc_stride; k += 64) row[k] = 0.0;

@@ -190,19 +190,92 @@ __device__ __forceinline__ float knn_bar_mfma(double tau, float uq2, float e) {
 //    the first 1 % of the models) shrink to the few models that really sit inside that ball.
 // FX: the feature count when it is a compile-time constant (5: the usual five bands), 0 = runtime F.
 // NWB: waves per block (they share the LDS tiles and meet at one barrier per tile; the default launch is ONE wave per block).
-template <int TILE, int FX, int NWB>
+// Scan state of one wave: the visiting order (outwards from the queries' own place, alternating sides), the batch of four
+// candidate tiles whose bounding boxes are in registers, and the reachable tiles of the last tested batch that have not been
+// taken yet.  (A plain struct with inlined members: lambdas capturing lambdas made the compiler keep this state in scratch.)
+template <int FL>
+struct KnnScan {
+    int nl, nr, ntiles, right;
+    int cand;                                             // this lane's candidate tile of the batch in registers: lane group c = lane >> 4 holds candidate c (-1: none)
+    int pend;                                             // ... of the batch that was tested last
+    fz_f4 bl0, bl1, bh0, bh1;                             // the candidate's box: lo[0..7], hi[0..7]
+    unsigned pmask;                                       // reachable candidates of the tested batch that have not been taken yet
+    // (no four-way selects over members here: the compiler turns them into indexed loads and moves the whole struct to scratch)
+    __device__ __forceinline__ int next_tile() {
+        if (nr >= ntiles && nl < 0) return -1;
+        int t;
+        if ((right && nr < ntiles) || nl < 0) t = nr++; else t = nl--;
+        right = 1 - right;
+        return t;
+    }
+    __device__ __forceinline__ void fetch(const float* bm, int sl) {
+        int m = -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int t = next_tile(); m = (sl == c) ? t : m; }
+        cand = m;
+        const fz_f4* bx = reinterpret_cast<const fz_f4*>(bm + (size_t)(m >= 0 ? m : 0) * FZ_KM_TSTR + 512);
+        bl0 = bx[0]; bl1 = bx[1]; bh0 = bx[2]; bh1 = bx[3];
+    }
+    // bit c: candidate c is within reach of some row (lane group c tests it: its 16 lanes are the 16 query rows)
+    __device__ __forceinline__ unsigned test(const float (&qlo)[FL], const float (&qhi)[FL], float barrow) const {
+        float lb = 0.f;
+#pragma unroll
+        for (int f = 0; f < FL; ++f) {
+            const float lo = f < 4 ? bl0[f & 3] : bl1[f & 3], hi = f < 4 ? bh0[f & 3] : bh1[f & 3];
+            const float m = fmaxf(fmaxf(lo - qhi[f], qlo[f] - hi), 0.f);        // the query's rounding already in qlo / qhi
+            lb = fmaf(m, m, lb);
+        }
+        const unsigned long long rm = __ballot(cand >= 0 && lb * 0.999999f <= barrow);
+        return ((rm & 0xffffull) ? 1u : 0u) | (((rm >> 16) & 0xffffull) ? 2u : 0u) | (((rm >> 32) & 0xffffull) ? 4u : 0u) | ((rm >> 48) ? 8u : 0u);
+    }
+    __device__ __forceinline__ int next_reachable(const float* bm, int sl, const float (&qlo)[FL], const float (&qhi)[FL], float barrow) {
+        while (true) {
+            if (pmask) {
+                const int c = __builtin_ctz(pmask);
+                pmask &= pmask - 1u;
+                return __builtin_amdgcn_readlane(pend, 16 * c);
+            }
+            if (__builtin_amdgcn_readfirstlane(cand) < 0) return -1;      // no batch left (candidate 0 is the first to run out)
+            pend = cand;
+            pmask = test(qlo, qhi, barrow);
+            fetch(bm, sl);                                 // the next batch's boxes travel while this batch's tiles are processed
+        }
+    }
+};
+
+// KPL > 0: ROW-PARALLEL ADMISSIONS.  The sorted list of query row R lives in the registers of the four lanes 4R .. 4R+3
+// (KPL consecutive entries each, k <= 4 KPL), so the wave holds its 16 lists as 16 independent "teams".  Pairs that pass
+// the exact fp64 re-check are not inserted one at a time by the whole wave (a serial LDS round trip + ~150 instructions
+// each: 3/4 of the kernel's instructions at M = 1e5) but appended to their row's small LDS queue; when a queue holds
+// FZ_KM_DT entries -- or the scan ends -- every team drains its own queue at the same time, one entry per round: compare
+// against its KPL entries, find the place with two quad-DPP moves, shift.  Rows whose queue is empty sit the round out.
+// Bars and k-th distances are refreshed once per drain, so between drains the screen is looser than it could be (a
+// superset is admitted; an entry that no longer belongs is a no-op for its team).  The lists are ordered by
+// (distance, original index) as before: the neighbour table does not depend on any of this.  KPL = 0: the lists stay in LDS
+// and the wave inserts one candidate at a time (k > 32).
+#ifndef FZ_KM_QC
+#define FZ_KM_QC 24                     // queue entries per row: FZ_KM_DT - 1 may wait when a step begins and a step adds at most 16 to one row
+#define FZ_KM_DT 8                      // drain when some row's queue holds this many
+#endif
+template <int TILE, int FX, int NWB, int KPL>
 static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
                                                          const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
                                                          const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd) {
     static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
+    static_assert(KPL == 0 || KPL == 5 || KPL == 8, "register lists: k <= 20 or k <= 32");
     constexpr int TF = FZ_KM_TSTR;
     constexpr int FL = FX ? FX : 6;                    // feature loop bound of the exact re-check
     __shared__ __attribute__((aligned(16))) float tA[TF];
     __shared__ __attribute__((aligned(16))) float tB[TF];
     __shared__ double qs[NWB][16][8];                   // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
+    __shared__ int qn[16];                              // KPL: entries waiting in each row's queue
     extern __shared__ double s_lists[];
+    // KPL: the per-row queues of admitted (distance, model) pairs reuse the lists' LDS -- the lists are only there while the
+    // seeds are ranked and when the result is written; in between they live in registers
+    double* qd = s_lists;                                // [16][FZ_KM_QC]
+    int* qj = reinterpret_cast<int*>(s_lists + 16 * FZ_KM_QC);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tree = blockIdx.y + tree0;
@@ -212,6 +285,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     double* Ld = s_lists + (size_t)wave * 16 * kpad;                                     // [16][kpad]
     int* Lj = reinterpret_cast<int*>(s_lists + (size_t)NWB * 16 * kpad) + (size_t)wave * 16 * kpad;
     for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
+    if (lane < 16) qn[lane] = 0;
     // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
     // qperm (may be null): the queries in Morton order -- the 16 queries of a wave are neighbours in feature space
     const int64_t islot = i0 + row < N ? i0 + row : N - 1;
@@ -272,14 +346,77 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     }
     const bool bar_lane = sl == (F & 3);
     // for the tile test: this lane's row in fp32 (+ the rounding that cost), and the row's bar in distance units
-    float qf[FL], eq[FL];
+    float qlo[FL], qhi[FL];
 #pragma unroll
-    for (int f = 0; f < FL; ++f) { qf[f] = (float)qs[wave][row][f]; eq[f] = 1.3e-7f * fabsf(qf[f]); }
+    for (int f = 0; f < FL; ++f) { const float qf = (float)qs[wave][row][f], eq = 2.0e-7f * fabsf(qf); qlo[f] = qf - eq; qhi[f] = qf + eq; }      // the conversion's rounding and that of qf -+ eq, with room
     float barrow;
     {
         const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
         barrow = knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
     }
+
+    // ---- row teams: the lists in registers, the drain ----
+    constexpr int KP = KPL ? KPL : 1;
+    double Lr[KP]; int Jr[KP];
+    const int team = lane >> 2, tl = lane & 3;
+    if constexpr (KPL > 0) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) { Lr[e] = Ld[team * kpad + tl * KPL + e]; Jr[e] = Lj[team * kpad + tl * KPL + e]; }   // kpad >= 4 KPL
+    }
+    auto quad_prev_i = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); };     // quad_perm [0,0,1,2]: lane t <- lane t - 1
+    auto quad_or = [](int v) __attribute__((always_inline)) {
+        v |= __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);       // [1,0,3,2]
+        v |= __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);       // [2,3,0,1]
+        return v;
+    };
+    auto refresh_bars = [&]() __attribute__((always_inline)) {                          // every lane: the bar of its row from the row's k-th distance
+        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
+        barrow = knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
+        const float ab = alpha - barrow;
+        if (bar_lane) { if (F < 4) a0 = ab; else a1 = ab; }
+    };
+    auto drain = [&]() __attribute__((always_inline)) {
+        if constexpr (KPL > 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int cnt = qn[team];
+            for (int h = 0; __any(h < cnt); ++h) {
+                const bool act = h < cnt;
+                const double dn = qd[team * FZ_KM_QC + (act ? h : 0)];
+                const int jn = qj[team * FZ_KM_QC + (act ? h : 0)];
+                int cb = 0, dup = 0;
+#pragma unroll
+                for (int e = 0; e < KPL; ++e) {
+                    cb += (Lr[e] < dn || (Lr[e] == dn && Jr[e] < jn)) ? 1 : 0;      // lexicographic (distance, index)
+                    dup |= (Jr[e] == jn) ? 1 : 0;                                   // a model already listed (a seed) is not listed twice
+                }
+                dup = quad_or(dup);
+                const int cbp = quad_prev_i(cb);
+                const int lh = quad_prev_i(__double2hiint(Lr[KPL - 1])), ll = quad_prev_i(__double2loint(Lr[KPL - 1]));
+                const int jl = quad_prev_i(Jr[KPL - 1]);
+                const bool first = (tl == 0) || (cbp == KPL);                      // the entry lands in this lane (else: the lower lane's last one moves up)
+                const double nd = first ? dn : __hiloint2double(lh, ll);
+                const int nj = first ? jn : jl;
+                if (act && !dup && cb < KPL) {
+#pragma unroll
+                    for (int e = KPL - 1; e >= 0; --e) {
+                        const bool sh = e > cb, at = e == cb;
+                        Lr[e] = sh ? Lr[e > 0 ? e - 1 : 0] : (at ? nd : Lr[e]);
+                        Jr[e] = sh ? Jr[e > 0 ? e - 1 : 0] : (at ? nj : Jr[e]);
+                    }
+                }
+            }
+            // the k-th distance of every row, then the bars
+            // (one predicated store per slot: a select chain over the slots becomes an indexed load and the list goes to scratch)
+            const int ke = k - 1;
+#pragma unroll
+            for (int e = 0; e < KPL; ++e)
+                if (tl * KPL + e == ke) qs[wave][team][6] = Lr[e] < bound2 ? Lr[e] : bound2;
+            if (tl == 0) qn[team] = 0;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            refresh_bars();
+        }
+    };
 
     const int ntiles = (M + TILE - 1) / TILE;
     // Visiting order.  The set's models are stored in Morton order (upload) and the wave's queries are neighbours
@@ -288,23 +425,24 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     // the rest of the scan admits little (benchmark data: 55-65 admissions per query instead of 87).  The lists are
     // ordered by (distance, original index), so the result does not depend on the order.  One wave per block only:
     // waves sharing tiles would need a common start.
-    int nl = -1, nr = 0, home = 0;                        // next tile on the left / right of the start
+    // Tile skipping.  Every 64-model tile carries its bounding box (behind its operands in HBM).  The boxes of the next FOUR
+    // tiles of the visiting order are tested at once -- lane group c = lane >> 4 takes candidate c, its 16 lanes the 16 query
+    // rows: lower bound of the distance from the row's query to the box against the row's bar -- straight from global memory
+    // (64 B per tile, L2-resident), and only tiles within reach of some row are staged into LDS and multiplied.  The boxes of
+    // the following batch are requested before the current batch's tiles are processed.  (Before: every tile of a
+    // reachable group of eight was staged, 2 KB, to read its box from LDS: 59 % of all tiles staged for 18 % multiplied, and
+    // the per-tile test + staging + barrier was two thirds of the kernel's instructions.)
+    KnnScan<FL> sc;
+    sc.nl = -1; sc.nr = 0; sc.ntiles = ntiles; sc.right = 1; sc.pmask = 0u; sc.pend = -1;
     if (NWB == 1 && ktab) {
         double qm[8];
 #pragma unroll
         for (int f = 0; f < 6; ++f) qm[f] = qs[wave][8][f];
         const int hm = ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
-        nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); nl = nr - 1;
+        sc.nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); sc.nl = sc.nr - 1;
     }
-    home = nr;
-    bool right = true;
-    auto next_tile = [&]() -> int {
-        int t;
-        if ((right && nr < ntiles) || nl < 0) t = nr++; else t = nl--;
-        right = !right;
-        return t;
-    };
-    auto stage = [&](int tile, float* dst) {             // 2176 contiguous bytes: 136 16-byte chunks over the wave's 64 lanes
+    sc.fetch(bm, sl);
+    auto stage = [&](int tile, float* dst) __attribute__((always_inline)) {             // 2176 contiguous bytes: 136 16-byte chunks over the wave's 64 lanes
         const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -313,7 +451,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                                                  (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
     };
     // admission path.  pm: this lane's 16-bit mask of (g, r) products under the bar.
-    auto slow = [&](unsigned pm, const float* blk, int jb) {
+    auto slow = [&](unsigned pm, const float* blk, int jb) __attribute__((always_inline)) {
         while (__any(pm != 0u)) {
             // every lane with something left takes its lowest pair: query row 4 sl + r, model 16 g + col of the step
             const bool has = pm != 0u;
@@ -329,7 +467,17 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
             double d2 = 0.0;
 #pragma unroll
             for (int f = 0; f < FL; ++f) { const double d = (FX || f < F) ? qv[f] - (double)pv[f] : 0.0; d2 = fma(d, d, d2); }
-            unsigned long long cm = __ballot(has && jpos < M && d2 <= taur && d2 < bound2);
+            const bool adm = has && jpos < M && d2 <= taur && d2 < bound2;
+            if constexpr (KPL > 0) {
+                int slot = 0;
+                if (adm) {
+                    slot = atomicAdd(&qn[R], 1);                   // < FZ_KM_QC: queues are drained from FZ_KM_DT entries on, a step adds <= 16 per row
+                    qd[R * FZ_KM_QC + slot] = d2; qj[R * FZ_KM_QC + slot] = j;
+                }
+                if (__any(adm && slot + 1 >= FZ_KM_DT)) drain();
+                continue;
+            }
+            unsigned long long cm = __ballot(adm);
             while (cm) {                                             // one candidate at a time into its row's sorted list
                 const int s1 = __builtin_ctzll(cm);
                 cm &= cm - 1;
@@ -361,37 +509,11 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
             }
         }
     };
-    int cur_t = next_tile(), nxt_t = 0;
-    auto run_tile = [&](const float* cur, float* nxt) -> bool {
-        const bool more = nr < ntiles || nl >= 0;         // tiles left on either side (before this tile's group test)
-        if (more) { nxt_t = next_tile(); stage(nxt_t, nxt); }
+    int cur_t = sc.next_reachable(bm, sl, qlo, qhi, barrow);
+    auto run_tile = [&](const float* cur, float* nxt) __attribute__((always_inline)) -> bool {
+        const int nx = sc.next_reachable(bm, sl, qlo, qhi, barrow);     // (tested against the bars as they are now: a superset of what will still matter)
+        if (nx >= 0) stage(nx, nxt);
         const int t = cur_t;
-        // lower bound of the distance from this lane's query to the tile's bounding box; the tile is skipped when it
-        // exceeds the bar of every row of the wave (then no model in it can be admitted: bar > tau >= the k-th distance)
-        auto box_reach = [&](const float* bx) -> bool {
-            const fz_f4 l0 = *reinterpret_cast<const fz_f4*>(bx), l1 = *reinterpret_cast<const fz_f4*>(bx + 4);
-            const fz_f4 h0 = *reinterpret_cast<const fz_f4*>(bx + 8), h1 = *reinterpret_cast<const fz_f4*>(bx + 12);
-            float lb = 0.f;
-#pragma unroll
-            for (int f = 0; f < FL; ++f) {
-                const float lo = f < 4 ? l0[f & 3] : l1[f & 3], hi = f < 4 ? h0[f & 3] : h1[f & 3];
-                float m = fmaxf(fmaxf(lo - qf[f], qf[f] - hi), 0.f);
-                m = fmaxf(m - eq[f], 0.f);
-                lb = fmaf(m, m, lb);
-            }
-            return __any(lb * 0.999999f <= barrow);
-        };
-        // entering an aligned group of tiles from its near end: if the whole group is out of reach, the scan's pointer on
-        // this side jumps over it (its remaining tiles are never staged)
-        const bool rside = t >= home;
-        if ((rside && (t % FZ_KM_GT) == 0) || (!rside && (t % FZ_KM_GT) == FZ_KM_GT - 1)) {
-            if (!box_reach(cur + 528)) {
-                if (rside) { const int e = (t / FZ_KM_GT + 1) * FZ_KM_GT; nr = nr > e ? nr : e; }
-                else { const int e = (t / FZ_KM_GT) * FZ_KM_GT - 1; nl = nl < e ? nl : e; }
-            }
-        }
-        const bool reach = box_reach(cur + 512);
-        if (reach) {
         fz_f4 nb0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
         fz_f4 nb1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
 #pragma unroll 2
@@ -420,16 +542,23 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                 slow(pm, cur + s * 512, t * TILE + s * 64);
             }
         }
-        }
-        cur_t = nxt_t;
+        cur_t = nx;
         __syncthreads();
-        return more;
+        return nx >= 0;
     };
-    stage(cur_t, tA);
-    __syncthreads();
-    while (true) {
-        if (!run_tile(tA, tB)) break;
-        if (!run_tile(tB, tA)) break;
+    if (cur_t >= 0) {
+        stage(cur_t, tA);
+        __syncthreads();
+        while (true) {
+            if (!run_tile(tA, tB)) break;
+            if (!run_tile(tB, tA)) break;
+        }
+    }
+    if constexpr (KPL > 0) {
+        drain();
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) { Ld[team * kpad + tl * KPL + e] = Lr[e]; Lj[team * kpad + tl * KPL + e] = Jr[e]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
     }
     for (int R = 0; R < 16; ++R) {
         const int64_t i = __shfl(qi, R, 64);

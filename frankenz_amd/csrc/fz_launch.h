@@ -83,8 +83,12 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     const size_t lds = ((size_t)FZ_TABS_DOUBLES + (size_t)NW * kv.acc_stride) * 8;
     const bool vec2 = (M % 2 == 0) && (((uintptr_t)plane & 15) == 0);
     const bool ho = kv.kmode == KDE_HIST;              // single-kernel label sets: the instantiation without the window code
-    auto kern = vec2 ? (ho ? k_plane_fused<NW, 2, true> : k_plane_fused<NW, 2, false>)
-                     : (ho ? k_plane_fused<NW, 1, true> : k_plane_fused<NW, 1, false>);
+    // the weights below wt_thresh of the best in fp32 unless the caller asked for the all-fp64 logsumexp (or thresholds nothing)
+    const bool x32 = !ko->exact_evidence && !c->exact_evidence && !getenv("FZ_EXACT_EVIDENCE") && ko->wt_thresh > 0.0;
+    auto kern = x32 ? (vec2 ? (ho ? k_plane_fused<NW, 2, true, true> : k_plane_fused<NW, 2, false, true>)
+                            : (ho ? k_plane_fused<NW, 1, true, true> : k_plane_fused<NW, 1, false, true>))
+                    : (vec2 ? (ho ? k_plane_fused<NW, 2, true, false> : k_plane_fused<NW, 2, false, false>)
+                            : (ho ? k_plane_fused<NW, 1, true, false> : k_plane_fused<NW, 1, false, false>));
     int64_t blocks = 0;
     if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

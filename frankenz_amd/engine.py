@@ -34,15 +34,16 @@ def kde_opts(kde_kwargs, normalize=True):
     kw = dict(kde_kwargs or {})
     wt = kw.pop("wt_thresh", 1e-3)
     cdf = kw.pop("cdf_thresh", 2e-4)
+    ex = int(bool(kw.pop("exact_evidence", False)))         # extension: the whole logsumexp in fp64
     kw.pop("sig_thresh", None)
     kw.pop("dx", None)
     if kw:
         raise NotImplementedError("kde_kwargs %s are not supported" % sorted(kw))
     if wt is None and cdf is None:
-        return KdeOpts(-np.inf, 1, int(normalize), 0.0)
+        return KdeOpts(-np.inf, 1, int(normalize), 0.0, ex, 0)
     if wt is None:
-        return KdeOpts(0.0, 0, int(normalize), float(cdf))
-    return KdeOpts(float(wt), 1, int(normalize), 0.0 if cdf is None else float(cdf))
+        return KdeOpts(0.0, 0, int(normalize), float(cdf), ex, 0)
+    return KdeOpts(float(wt), 1, int(normalize), 0.0 if cdf is None else float(cdf), ex, 0)
 
 
 def _f64(a):

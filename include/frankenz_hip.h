@@ -61,6 +61,10 @@ typedef struct fz_kde_opts {
     int32_t normalize;     /* 1: pdf /= pdf.sum() (bruteforce.py:370, 629)      */
     double  cdf_thresh;    /* CDF rule: keep the ascending prefix with
                               cdf <= 1 - cdf_thresh (default 2e-4)              */
+    int32_t exact_evidence;/* extension, default 0: as fz_like_opts.exact_evidence, for the calls that take
+                              no likelihood options (predict from stored ln-weights): 1 = the whole
+                              logsumexp in fp64; 0 = the weights below wt_thresh of the best in fp32  */
+    int32_t reserved_;     /* keep 0 */
 } fz_kde_opts;
 
 /* accumulated device time per kernel family since fz_timing_reset (HIP events on

@@ -33,7 +33,7 @@ def test_build_and_load_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from frankenz_amd._lib import KdeOpts, LikeOpts, Timing
     assert ctypes.sizeof(LikeOpts) == 32 and LikeOpts.ltol.offset == 16 and LikeOpts.exact_evidence.offset == 24
-    assert ctypes.sizeof(KdeOpts) == 24 and KdeOpts.cdf_thresh.offset == 16
+    assert ctypes.sizeof(KdeOpts) == 32 and KdeOpts.cdf_thresh.offset == 16 and KdeOpts.exact_evidence.offset == 24
     assert ctypes.sizeof(Timing) == 7 * 16
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import frankenz_oracle as fo
-from conftest import EVID, load_golden
+from conftest import EVID, EVID64, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -270,7 +270,7 @@ def test_wild_values_take_the_ieee_variant(kw):
                                                  label_dict=od, **kw)
     close(bf.fit_chi2, rf['chi2'], rtol=1e-9, atol=1e-9)
     close(bf.fit_lnlike, rf['lnlike'], rtol=1e-9, atol=1e-9)
-    close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
+    close(lm, rlm, rtol=1e-9); close(le, rle, **EVID64)          # the IEEE variant is all fp64
     close(p, rp, rtol=1e-8, atol=1e-13)
 
 
@@ -320,7 +320,7 @@ def test_cdf_threshold_rule_through_the_classes(kw):
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od,
                                              kde_kwargs=kk, **kw)
     tol = dict(rtol=1e-7, atol=1e-13)
-    close(p, rp, **tol); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
+    close(p, rp, **tol); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID64)      # materialised rows: all fp64
     close(bf.predict(z, ze, label_dict=d, kde_kwargs=kk, verbose=False), rp, **tol)
     if kw.get('free_scale') and not kw.get('ignore_model_err'):
         return
@@ -356,7 +356,7 @@ def test_wide_band_sets_unmasked(B, kw):
                                  lprob_kwargs=kw, return_gof=True, verbose=False, save_fits=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
-    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID)
+    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID64)      # padded band counts: the all-fp64 ln-space bodies
     bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
     rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
     close(bf.fit_lnprob, rf['lnlike'], rtol=1e-8, atol=1e-8)
@@ -461,9 +461,10 @@ def test_band_constant_model_errors_take_the_hoisted_path(kw, errs, monkeypatch)
     np.testing.assert_array_equal(a[5], rf['Ndim'])
 
 
-@pytest.mark.parametrize('env', [{'FZ_FUSED_CFG': '4,8'}, {'FZ_FUSED_CFG': '2,8'}, {'FZ_FUSED_CFG': '2,16'},
-                                 {'FZ_FUSED_CFG': '1,4'}, {'FZ_NO_WSPACE': '1'}, {'FZ_CHUNK': '5000'},
-                                 {'FZ_NO_WSPACE': '1', 'FZ_FUSED_CFG': '2,16'}])
+@pytest.mark.parametrize('env', [{'FZ_HIST': '0', 'FZ_FUSED_CFG': '4,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,16'},
+                                 {'FZ_HIST': '0', 'FZ_FUSED_CFG': '1,4'}, {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1'}, {'FZ_CHUNK': '5000'},
+                                 {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1', 'FZ_FUSED_CFG': '2,16'}, {'FZ_HIST': '0'},
+                                 {'FZ_HIST_CFG': '2,8'}, {'FZ_HIST_NOSCRB': '1'}, {'FZ_NOLIST': '1'}, {'FZ_HIST': '0', 'FZ_NOLIST': '1'}])
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
     """every launch geometry / kernel body / chunking reachable through the diagnostic
     environment switches gives the same PDFs (summation order aside)."""
@@ -648,9 +649,10 @@ def test_predict_from_stored_plane_single_pass(M, single_class, monkeypatch):
     lw[10, :] = lw[10, 0]                                    # all equal: every entry selected
     lw[11, :] += 1e6                                         # huge offsets: the threshold offset is absorbed
     bf = BruteForce(Y, Ye, Ym)
-    run = lambda: bf.predict(z, ze, label_dict=d, logwt=lw.copy(), return_gof=True, verbose=False)
+    run = lambda **kk: bf.predict(z, ze, label_dict=d, logwt=lw.copy(), return_gof=True, verbose=False, **kk)
     with np.errstate(all='ignore'):
-        p1, (lm1, le1) = run()
+        p0, (lm0, le0) = run()                                  # default: the sub-threshold weights in fp32 (conftest.EVID)
+        p1, (lm1, le1) = run(kde_kwargs={'exact_evidence': True})
         monkeypatch.setenv('FZ_PLANE_TWOPASS', '1')
         p2, (lm2, le2) = run()
         monkeypatch.delenv('FZ_PLANE_TWOPASS')
@@ -659,6 +661,9 @@ def test_predict_from_stored_plane_single_pass(M, single_class, monkeypatch):
     close(p1, p2, rtol=1e-10, atol=1e-16)
     close(lm1, rlm, rtol=0, atol=0); close(le1, rle, rtol=1e-12, atol=1e-11)
     close(p1, rp, rtol=1e-8, atol=1e-14)
+    close(lm0, lm1, rtol=0, atol=0); close(p0, p1, rtol=1e-10, atol=1e-16)
+    big = np.abs(rle) > 1e5                                     # (rows offset by 1e6: a relative tolerance is the meaningful one there)
+    close(le0[~big], rle[~big], **EVID); close(le0[big], rle[big], rtol=1e-12, atol=0)
     # wt_thresh = 0 keeps every entry with a non-zero weight; a large threshold keeps only the best
     for wt in (0.0, 0.5):
         with np.errstate(all='ignore'):
@@ -800,3 +805,63 @@ def test_list_free_form_for_broad_likelihoods(kw, force, monkeypatch):
     close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[:25].copy(), Xe[:25].copy(), Xm[:25].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     close(p1[:25], rp, rtol=1e-8, atol=1e-14); close(lm1[:25], rlm); close(le1[:25], rle, **EVID)
+
+
+@pytest.mark.parametrize('case', ['plain', 'free_scale', 'per_model_err', 'masked', 'prior', 'chunked', 'broad'])
+def test_exact_evidence_option_is_fp64_everywhere(case, monkeypatch):
+    """``lprob_kwargs={'exact_evidence': True}`` (fz_like_opts.exact_evidence) / ``kde_kwargs={'exact_evidence': True}``
+    (predict): every weight of the ln-evidence formed and summed in fp64, on every route -- k_hist<exact>, the masked
+    and ln-prior bodies, chunked and unchunked launches (which must then agree to rounding), predict from the stored
+    plane -- held to 1e-9 against the oracle (the default bodies: conftest.EVID)."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.pdf import logprob_prior
+    d, od = dicts()
+    rs = np.random.RandomState(4242)
+    M, N, B = 2600, 17000 if case == 'chunked' else 400, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = np.tile(0.5 * SDSS5, (M, 1)); Ym = np.ones((M, B))
+    noise = SDSS5 * (6.0 if case == 'broad' else 1.0)
+    X = Y[rs.choice(M, N)] + noise * rs.randn(N, B); Xe = np.tile(noise, (N, 1)); Xm = np.ones((N, B))
+    X[:4] = Y[:4]                                            # self matches
+    kw = {}
+    if case == 'free_scale':
+        kw = {'free_scale': True, 'ignore_model_err': True}
+    if case == 'per_model_err':
+        Ye = Ye * rs.uniform(0.5, 1.5, size=Ye.shape)
+    if case == 'masked':
+        Xm[rs.rand(N, B) < 0.1] = 0
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    kwx = dict(kw, exact_evidence=True)
+    extra = {}
+    if case == 'prior':
+        tab = np.log(rs.dirichlet(np.ones(M), size=3)); rows = rs.randint(0, 3, N)
+        extra = dict(lprob_func=logprob_prior(tab, rows))
+    run = lambda k: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=k,
+                                                      return_gof=True, save_fits=False, verbose=False, **extra)
+    p0, (lm0, le0) = run(kw)
+    p1, (lm1, le1) = run(kwx)
+    sel = slice(0, 120)
+    if case == 'prior':
+        lnp = fo.bruteforce_fit(X[sel].copy(), Xe[sel].copy(), Xm[sel].copy(), Y, Ye, Ym)['lnlike'] + tab[rows[sel]]
+        from scipy.special import logsumexp
+        rle = logsumexp(lnp, axis=1); rlm = lnp.max(axis=1)
+    else:
+        rp, rlm, rle = fo.bruteforce_fit_predict(X[sel].copy(), Xe[sel].copy(), Xm[sel].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+        close(p1[sel], rp, rtol=1e-8, atol=1e-14)
+    close(le1[sel], rle, **EVID64); close(lm1[sel], rlm, rtol=1e-9)
+    close(le0[sel], rle, **EVID)
+    close(p0, p1, rtol=1e-9, atol=1e-15); close(lm0, lm1, rtol=1e-12)
+    if case == 'chunked':
+        monkeypatch.setenv('FZ_CHUNK', '5000')
+        p2, (lm2, le2) = run(kwx)
+        monkeypatch.delenv('FZ_CHUNK')
+        np.testing.assert_array_equal(lm2, lm1)
+        close(le2, le1, rtol=1e-13, atol=1e-13); close(p2, p1, rtol=1e-12, atol=1e-16)        # summation order of the atomics aside
+    if case in ('plain', 'free_scale'):
+        # predict from the stored ln-prob plane: default (fp32 remainder) and exact
+        bf = BruteForce(Y, Ye, Ym)
+        bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
+        pa, (lma, lea) = bf.predict(z, ze, label_dict=d, return_gof=True, verbose=False)
+        pb, (lmb, leb) = bf.predict(z, ze, label_dict=d, kde_kwargs={'exact_evidence': True}, return_gof=True, verbose=False)
+        close(leb[sel], rle, **EVID64); close(lea[sel], rle, **EVID)
+        np.testing.assert_array_equal(lma, lmb); close(pa, pb, rtol=1e-10, atol=1e-16)
+        close(pb[sel], rp, rtol=1e-8, atol=1e-14)
