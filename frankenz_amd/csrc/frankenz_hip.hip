@@ -300,7 +300,7 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
                     const int64_t lpad = lo - (pp - w), hpad = hi - (pp + w + 1);
                     double mass = cdf[len + hpad - 1];
                     if (lpad != 0) mass -= cdf[lpad - 1];
-                    ntab[r * Gp + q] = mass;
+                    ntab[r * Gp + q] = mass > 0.0 ? mass : 1.0;       // a zero / underflowed mass: no model of this class stacks at q (the labels were checked), the row entry stays 0
                 }
                 ++r;
             }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         HistState<TW> hs;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = EXACT ? 0.0 : (double)INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
+            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
             hs.tthr[o] = -120.f; hs.pend[o] = 0; hs.namb[o] = 0;
         }
         hs.tick = 0; hs.next = 1;
@@ -296,10 +296,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             const bool valid = !TAIL || j < M;
                             const double w = valid ? hist_exactw<WP, false>(c2[0][o], tbx) : 0.0;
                             hs.S[o] += w;
-                            const bool up = w > hs.hi[o];           // (EXACT: hi holds the lane's best weight so far, lo its chi2; Sc the wave's bar)
-                            hs.hi[o] = up ? w : hs.hi[o];
-                            hs.lo[o] = up ? c2[0][o] : hs.lo[o];
-                            hs.Sc[o] = vmax_raw(hs.Sc[o], w);
+                            hs.Sc[o] = vmax_raw(hs.Sc[o], w);       // (EXACT: Sc holds the best weight seen: the bar of the ambiguous band, and ln-max at the end)
                             if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag[0] + w0], w);
                             const bool am = valid && !(w > thr_def) && (w >= wt_thresh * 0.999 * hs.Sc[o]);
                             const unsigned long long mask = __ballot(am);
@@ -391,16 +388,12 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 if constexpr (!EXACT) {
                     while (hs.pend[o] > 0) drain(o);
                 } else {
-                    wbest_run = wave_max(hs.hi[o]);
+                    wbest_run = wave_max(hs.Sc[o]);
                 }
                 double lbest;                                                  // exact ln-like of the best model
                 if constexpr (EXACT) {
-                    // the lane that holds the wave-wide best weight names the best model's chi2
-                    const unsigned long long who = __ballot(hs.hi[o] == wbest_run && wbest_run > 0.0);
-                    const int src_lane = who ? __builtin_ctzll(who) : 0;
-                    const double cb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hs.lo[o]), src_lane),
-                                                       __builtin_amdgcn_readlane(__double2loint(hs.lo[o]), src_lane));
-                    lbest = who ? uniform_d(src.lnl_of_chi2(cb)) : -INFINITY;
+                    // ln L of the best model = ln L(mode) + ln of its exact relative weight (4e-16 relative on the weight: 1e-16 on ln-max)
+                    lbest = (wbest_run > 0.0) ? uniform_d(lref + log_pos(wbest_run, tb)) : -INFINITY;
                 } else {
                     const double l = wave_max(hs.lo[o]), h = -wave_max(-hs.hi[o]);
                     const double ll = (l >= 0.0) ? src.lnl_of_chi2(l) : -INFINITY;

@@ -556,6 +556,45 @@ def g12():
     save('g12_catalogue_stack', **out)
 
 
+def g13():
+    """The law of the per-object redshift assignment of the Gibbs sweeps (samplers.py:498-499 / 519-520): the reference's
+    own hierarchical_sampler.sample() is run for one sweep with a recording stand-in for its RandomState, on 8 objects
+    (rows of g10's PDFs) repeated 12 500 times each, from pos_init = nz.  Stored: the ``pvals`` rows exactly as the
+    reference formed them (``p * pos / np.dot(p, pos)``) and the bin counts of its 12 500 ``multinomial(1, pvals)``
+    draws per object.  A draw stream cannot be reproduced by a kernel that takes one uniform per object (documented
+    deviation); its LAW can: the device draws are tested against these counts."""
+    from frankenz import samplers
+    g = np.load(os.path.join(HERE, 'g10_summarize.npz'))
+    pd = np.ascontiguousarray(g['pdfs_in'], dtype=float)
+    pd = pd / pd.sum(axis=1)[:, None]
+    pick = np.array([0, 3, 7, len(pd) - 6, len(pd) - 5, len(pd) - 3, len(pd) - 2, len(pd) - 1])    # fitted PDFs, bimodal, edge-peaked, flat, single bin, broad
+    reps = 12500
+    rs0 = np.random.RandomState(13)
+    nz = rs0.dirichlet(np.full(pd.shape[1], 0.7))
+
+    class Recorder(object):
+        def __init__(self, seed):
+            self.rs = np.random.RandomState(seed); self.pvals = []; self.draws = []
+        def multinomial(self, n, pvals):
+            out = self.rs.multinomial(n, pvals)
+            if n == 1:
+                self.pvals.append(np.array(pvals)); self.draws.append(int(np.argmax(out)))
+            return out
+        def dirichlet(self, a):
+            return self.rs.dirichlet(a)
+    rec = Recorder(131)
+    sampler = samplers.hierarchical_sampler(np.repeat(pd[pick], reps, axis=0))
+    next(sampler.sample(1, pos_init=nz.copy(), thin=1, rstate=rec))
+    # the generator draws once before the loop and once inside it: keep the first sweep (from pos_init)
+    n = len(pick) * reps
+    pv = np.array(rec.pvals[:n]); dr = np.array(rec.draws[:n])
+    counts = np.zeros((len(pick), pd.shape[1]), dtype=np.int32)
+    for k in range(len(pick)):
+        assert np.array_equal(pv[k * reps], pv[k * reps + reps - 1])
+        counts[k] = np.bincount(dr[k * reps:(k + 1) * reps], minlength=pd.shape[1])
+    save('g13_nz_assign_law', pdfs=pd[pick], nz=nz, pvals=pv[::reps], counts=counts, reps=np.array(reps))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for nm in sys.argv[1:]:
@@ -564,6 +603,6 @@ if __name__ == '__main__':
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
-    which = sys.argv[1:] or ['g%d' % k for k in range(1, 13)]
+    which = sys.argv[1:] or ['g%d' % k for k in range(1, 14)]
     for name in which:
         globals()[name]()

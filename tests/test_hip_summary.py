@@ -163,3 +163,33 @@ def test_nz_assign_categorical_draw():
     assert c1[350] == 3 and c1.sum() == 3
     with pytest.raises(ValueError):
         samplers.nz_assign(nz, pdfs, u=np.full(N, 1.0))
+
+
+def _two_sample_chi2(a, b):
+    """chi-square statistic and degrees of freedom of two equal-size samples of one multinomial law"""
+    keep = (a + b) >= 10
+    stat = np.sum((a[keep] - b[keep]) ** 2 / (a[keep] + b[keep]).astype(float))
+    return stat, max(int(keep.sum()) - 1, 1), (a[~keep].sum(), b[~keep].sum())
+
+
+def test_nz_assign_law_against_the_reference_draws():
+    """golden g13: the reference's own sampler (samplers.py:498-499) ran 12 500 ``multinomial(1, pvals)`` draws per object
+    for 8 objects.  (i) the weights the device draws from, p * nz / dot(p, nz), equal the reference's ``pvals`` rows;
+    (ii) 12 500 device draws per object (one uniform each) follow the same law: two-sample chi-square against the
+    reference's bin counts inside a 5-sigma bound, no draw in a bin the reference gives no mass."""
+    from frankenz_amd import samplers
+    g = load_golden('g13_nz_assign_law')
+    pd, nz, pv, rc, reps = g['pdfs'], g['nz'], g['pvals'], g['counts'].astype(np.int64), int(g['reps'])
+    w = pd * nz
+    np.testing.assert_allclose(w / w.sum(axis=1)[:, None], pv, rtol=1e-13, atol=1e-300)
+    K, G = pd.shape
+    big = np.repeat(pd, reps, axis=0)
+    u = np.random.RandomState(1313).rand(len(big))
+    counts, bins = samplers.nz_assign(nz, big, u=u, return_bins=True)
+    assert counts.sum() == len(big) and (bins >= 0).all()
+    for k in range(K):
+        dc = np.bincount(bins[k * reps:(k + 1) * reps], minlength=G).astype(np.int64)
+        assert dc[pv[k] == 0].sum() == 0
+        stat, dof, rare = _two_sample_chi2(dc, rc[k])
+        assert stat < dof + 5 * np.sqrt(2 * dof) + 10, (k, stat, dof)
+        assert abs(int(rare[0]) - int(rare[1])) < 10 + 5 * np.sqrt(rare[0] + rare[1] + 1)

@@ -352,3 +352,34 @@ def test_g12_catalogue_stack(tag):
     stack = g[tag + '_stack']
     ll, ov = fo.loglike_nz(stack / stack.sum(), pd)
     eq(ov, g[tag + '_overlap_stack'][::10], rtol=1e-12, atol=0)
+
+
+def test_g13_nz_assign_law_of_the_oracle():
+    """the oracle's inverse-CDF draw against the reference sampler's own pvals and multinomial(1, .) counts (g13)"""
+    g = load_golden('g13_nz_assign_law')
+    pd, nz, pv, rc, reps = g['pdfs'], g['nz'], g['pvals'], g['counts'].astype(np.int64), int(g['reps'])
+    w = pd * nz
+    np.testing.assert_allclose(w / w.sum(axis=1)[:, None], pv, rtol=1e-13, atol=1e-300)
+    rs = np.random.RandomState(77)
+    for k in range(len(pd)):
+        _, bins, _ = fo.nz_assign(nz, np.repeat(pd[k:k + 1], reps, axis=0), rs.rand(reps))
+        dc = np.bincount(bins, minlength=pd.shape[1]).astype(np.int64)
+        keep = (dc + rc[k]) >= 10
+        stat = np.sum((dc[keep] - rc[k][keep]) ** 2 / (dc[keep] + rc[k][keep]).astype(float))
+        dof = max(int(keep.sum()) - 1, 1)
+        assert dc[pv[k] == 0].sum() == 0 and stat < dof + 5 * np.sqrt(2 * dof) + 10, (k, stat, dof)
+
+
+def test_knn_limits_are_refused_loudly_where_the_reference_would_run():
+    """knn.py:190-193 takes any k; the GPU search keeps k <= 64 and K k <= 512 (register / LDS budget of the subset kernel):
+    beyond that the call must fail before any work, with the limits in the message -- never a silent truncation."""
+    from frankenz_amd import NearestNeighbors
+    rs = np.random.RandomState(3)
+    Y = rs.lognormal(1, 1, (300, 5)); Ye = 0.05 * Y; Ym = np.ones_like(Y)
+    nn = NearestNeighbors(Y, Ye, Ym, K=9, feature_map='identity', rstate=np.random.RandomState(1), verbose=False)
+    X = Y[:4] + 0.1
+    for k in (65, 57):                      # k > 64; K k = 513 > 512
+        with pytest.raises(NotImplementedError, match='k <= 64 and K\\*k <= 512'):
+            nn.fit(X, 0.1 * np.ones_like(X), np.ones_like(X), k=k, verbose=False)
+        with pytest.raises(NotImplementedError, match='k <= 64 and K\\*k <= 512'):
+            nn.fit_predict(X, 0.1 * np.ones_like(X), np.ones_like(X), np.zeros(300), np.ones(300), label_grid=np.arange(5.), k=k, verbose=False)

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Full measurement set for profiles/ (run through gpurun; writes gpurun_out/m_*).
+# Full measurement set for profiles/ (run through gpurun; writes gpurun_out/m_*).  Release build only.
 #   ./tools/measure.sh
 export TMPDIR=/tmp
 export FZ_BENCH_NO_EXTRA=1
 O=gpurun_out
 mkdir -p $O
 FZ_BENCH_NO_EXTRA= python3 bench.py > $O/m_bench_fit_predict_modeA.json 2> $O/m_bench_fit_predict_modeA.err
-FZ_NO_WSPACE=1 FZ_BENCH_NO_EXTRA=1 python3 bench.py --no-cpu > $O/m_bench_fit_predict_modeA_all_fp64_body.json 2>/dev/null
+python3 bench.py --exact --no-cpu > $O/m_bench_fit_predict_modeA_exact_evidence.json 2>/dev/null
+FZ_HIST=0 python3 bench.py --no-cpu > $O/m_bench_fit_predict_modeA_k_fused_round2_kernel.json 2>/dev/null
 python3 bench.py --noise-scale 3 --nobj 262144 --no-cpu > $O/m_bench_fit_predict_noise3.json 2>/dev/null
 python3 bench.py --noise-scale 10 --nobj 262144 --no-cpu > $O/m_bench_fit_predict_noise10.json 2>/dev/null
 python3 bench.py --model-err varying --no-cpu > $O/m_bench_fit_predict_modeA_varying_model_errors.json 2>/dev/null
@@ -22,10 +23,11 @@ python3 bench.py --label-err varying --nobj 262144 --no-cpu --steps 2 > $O/m_ben
 python3 bench.py --mode C --model-err varying --nobj 20000 --nmodel 10000 --no-cpu --steps 2 > $O/m_bench_fit_predict_modeC.json 2>/dev/null
 python3 bench.py --workload knn --nobj 100000 --no-cpu > $O/m_bench_knn.json 2>/dev/null
 python3 bench.py --workload summarize --nobj 1000000 --no-cpu > $O/m_bench_summarize.json 2>/dev/null
+for nb in 4 6 7 8; do python3 bench.py --nband $nb --nobj 262144 --no-cpu --steps 2 > $O/m_bench_fit_predict_${nb}bands.json 2>/dev/null; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_headline -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/m_stats_headline.log 2>&1
+FZ_BENCH_NO_EXTRA= rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_default_line -- python3 bench.py --no-cpu > $O/m_stats_default_line.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_summarize -- python3 bench.py --workload summarize --nobj 1000000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_summarize.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_planes -- python3 bench.py --workload fit --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_planes.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_predict -- python3 bench.py --workload predict --nobj 100000 --nmodel 10000 --no-cpu --steps 5 --warmup 1 > $O/m_stats_predict.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_knn -- python3 bench.py --workload knn --nobj 100000 --no-cpu --steps 3 --warmup 1 > $O/m_stats_knn.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/m_stats_many_widths -- python3 bench.py --label-err varying --nobj 262144 --no-cpu --steps 2 --warmup 1 > $O/m_stats_many_widths.log 2>&1
 tail -c 600 $O/m_bench_fit_predict_modeA.json
