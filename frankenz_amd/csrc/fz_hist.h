@@ -143,7 +143,10 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     __shared__ tag_t s_tag[EXACT ? 2 : NOBJ * CAP];
     // EXACT has no rings and keeps the full log / exp tables in LDS (every pair takes an exp); the screen form a 256-entry exp table
     __shared__ __attribute__((aligned(16))) double s_tabs[EXACT ? FZ_TABS_DOUBLES : FZ_HEXP_K];
-    __shared__ __attribute__((aligned(16))) double s_objs[NOBJ * OD];
+    // the parked object rows are only read once, right after the first barrier of a round (into registers): in the screen form
+    // they share the LDS of the wave's candidate buffer, which is empty then (all settled at the end of the previous round)
+    __shared__ __attribute__((aligned(16))) double s_objs[EXACT ? NOBJ * OD : 2];
+    static_assert(EXACT || TW * OD <= TW * CAP, "an object row must fit its candidate buffer");
     extern __shared__ double s_rows[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     const KdeView kv = *kvp;
     const int32_t* posw = kv.pos;
     const int w0 = kv.w0;
-    double* objs = s_objs + wave * (TW * OD);
+    double* objs = EXACT ? s_objs + wave * (TW * OD) : s_c2 + wave * (TW * CAP);
     double* rows = s_rows + (size_t)wave * TW * acc_stride;
     double* rc2 = s_c2 + (EXACT ? 0 : wave * (TW * CAP));
     tag_t* rtag = s_tag + (EXACT ? 0 : wave * (TW * CAP));

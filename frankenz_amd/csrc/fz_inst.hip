@@ -97,54 +97,117 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
 // mode C driver on a prepared chunk: leaves converged state in c->d_mc[*]
 // ---------------------------------------------------------------------------
 template <int BT, bool MASKED>
-static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetView& sub) {
+static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetView& sub, bool tame) {
     const int64_t M = sub.nbr ? sub.W : c->M;
     const size_t pl = (size_t)n * M * 8;
     for (int k = 0; k < 4; ++k) FZCHK(c->d_mc[k].ensure(pl));
-    FZCHK(c->d_mcerr.ensure(n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(2 * n * 4)); FZCHK(c->d_mccnt.ensure(64));
+    FZCHK(c->d_mcerr.ensure(2 * n * 8)); FZCHK(c->d_mcfn.ensure(n * 4)); FZCHK(c->d_mcact.ensure(4 * n * 4)); FZCHK(c->d_mccnt.ensure(64));
     if (n > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
-    st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.firstnan = c->d_mcfn.as<int>();
+    st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.errhi = st.err + n; st.firstnan = c->d_mcfn.as<int>();
     // Active-object lists and their lengths live on the device and alternate between two slots; the host
     // queues FZ_MODEC_BURST iterations (step + stop rule, launched for the object count it last saw: blocks
     // of objects that stopped since exit at once) before it looks at the count again, so the loop is not
     // paced by one host round trip per iteration (a quarter of the time before).
     int* lists[2] = {c->d_mcact.as<int>(), c->d_mcact.as<int>() + n};
-    int* counts = c->d_mccnt.as<int>();                  // [0], [1]: list lengths; [2]: last iteration that left objects active
+    int* counts = c->d_mccnt.as<int>();                  // [0], [1]: list lengths; [2]: last iteration that left objects active; [3]: ambiguous objects
     HIPCHK(hipMemsetAsync(counts, 0, 16, c->stream));
-    HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
+    HIPCHK(hipMemsetAsync(st.err, 0, 2 * n * 8, c->stream));
     HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
-    st.list = nullptr; st.ncur = nullptr; st.list_next = lists[0]; st.nactive = counts; st.last_iter = counts + 2;
+    // the reciprocal-based solve for mask-free tame data (fz_modec.h); FZ_MODEC_IEEE=1 keeps the IEEE divisions throughout
+    const bool fast = !MASKED && tame && !getenv("FZ_MODEC_IEEE");
+    st.amb = fast ? c->d_mcact.as<int>() + 2 * n : nullptr; st.namb = counts + 3; st.ambflag = fast ? c->d_mcact.as<int>() + 3 * n : nullptr;
+    if (fast) HIPCHK(hipMemsetAsync(st.ambflag, 0, n * 4, c->stream));
     ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B; mc.sub = sub;
     const int64_t tiles = (M + 255) / 256;
     if (n * tiles > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
     const int burst = getenv("FZ_MODEC_BURST") ? std::max(1, atoi(getenv("FZ_MODEC_BURST"))) : 8;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
-    hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(n * tiles)), dim3(256), 0, c->stream, mc, st, n, M, 1);
-    // iteration 0 runs on every object (list == nullptr); iteration t >= 1 on list t & 1 ... written by the check of t - 1
-    int it = 0, nact = (int)n;        // nact: an upper bound of the active count
-    bool first = true;
-    while (nact > 0) {
-        if (it >= max_iter)
-            return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
-                            "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
-        for (int b = 0; b < burst && it < max_iter; ++b, ++it) {
-            const int cur = it & 1, nxt = cur ^ 1;
-            st.list = first ? nullptr : lists[cur]; st.ncur = first ? nullptr : counts + cur;
-            st.list_next = lists[nxt]; st.nactive = counts + nxt;
-            HIPCHK(hipMemsetAsync(counts + nxt, 0, 4, c->stream));
-            hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>>), dim3((unsigned)(nact * tiles)), dim3(256), 0, c->stream, mc, st, nact, M, 0);
-            hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((nact + 255) / 256)), dim3(256), 0, c->stream, st, nact, o->ltol, it + 1);
-            first = false;
-        }
-        HIPCHK(hipMemcpyAsync(&nact, counts + (it & 1), 4, hipMemcpyDeviceToHost, c->stream));
+    int it_max = 0;
+    if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
+        // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
+        const size_t lds = (size_t)M * 8;
+        auto launch = [&](auto kern, int T, const int* list, int64_t nobj) -> int {
+            HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int bpc = 1;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, T, lds));
+            const int64_t blocks = std::min<int64_t>(nobj, (int64_t)std::max(1, bpc) * c->cu_count);
+            ModeCState s2 = st; s2.last_iter = counts + 2; s2.list = list; s2.namb = counts + 3;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c->stream, mc, s2, nobj, (int)M, o->ltol, max_iter, counts + 1);
+            return 0;
+        };
+        auto run = [&](auto fastc, const int* list, int64_t nobj) -> int {
+            constexpr bool F = decltype(fastc)::value;
+            using MCT = ModeC<BT, MASKED>;
+            if (M <= 1024) return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, list, nobj);
+            if (M <= 4096) return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, list, nobj);
+            if (M <= 768 * 14) return launch(k_modec_persist<MCT, F, 768, 14>, 768, list, nobj);
+            return launch(k_modec_persist<MCT, F, 512, 32>, 512, list, nobj);
+        };
+        if (fast) FZCHK(run(std::true_type{}, nullptr, n)); else FZCHK(run(std::false_type{}, nullptr, n));
+        int res[3] = {0, 0, 0};                              // status, slowest object's iterations, ambiguous objects
+        HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (fast && res[2] > 0 && !res[0]) {
+            FZCHK(run(std::false_type{}, st.amb, res[2]));
+            HIPCHK(hipMemcpyAsync(res, counts + 1, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        HIPCHK(hipGetLastError());
+        if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
+                                    "(the reference loop at pdf.py:199 would not terminate)", max_iter);
+        c->tm.n_modec += res[1];         // iterations of the slowest object (the two timed scopes add the other two counts the bench subtracts)
+        return 0;
     }
-    HIPCHK(hipMemcpyAsync(&it, counts + 2, 4, hipMemcpyDeviceToHost, c->stream));      // iterations the slowest object took, minus one
+    // one run of the fixed point over `n0` objects (all of the chunk, or the listed ones), to convergence
+    auto iterate = [&](const int* list0, int n0, bool fst) -> int {
+        auto step = [&](const ModeCState& s2, int nobj, int init) {
+            if (fst) hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>, true>), dim3((unsigned)(nobj * tiles)), dim3(256), 0, c->stream, mc, s2, nobj, M, init);
+            else hipLaunchKernelGGL((k_modec_step<ModeC<BT, MASKED>, false>), dim3((unsigned)(nobj * tiles)), dim3(256), 0, c->stream, mc, s2, nobj, M, init);
+        };
+        ModeCState s2 = st;
+        if (!fst) s2.amb = nullptr;
+        s2.list = list0; s2.ncur = nullptr; s2.list_next = lists[0]; s2.nactive = counts; s2.last_iter = counts + 2;
+        HIPCHK(hipMemsetAsync(counts, 0, 8, c->stream));
+        step(s2, n0, 1);
+        // iteration 0 runs on the initial set; iteration t >= 1 on list t & 1 ... written by the check of t - 1
+        int it = 0, nact = n0;        // nact: an upper bound of the active count
+        bool first = true;
+        while (nact > 0) {
+            if (it >= max_iter)
+                return fail(-7, "mode C (free_scale with model errors): %d objects not converged after %d iterations "
+                                "(the reference loop at pdf.py:199 would not terminate)", nact, max_iter);
+            for (int b = 0; b < burst && it < max_iter; ++b, ++it) {
+                const int cur = it & 1, nxt = cur ^ 1;
+                s2.list = first ? list0 : lists[cur]; s2.ncur = first ? nullptr : counts + cur;
+                s2.list_next = lists[nxt]; s2.nactive = counts + nxt;
+                HIPCHK(hipMemsetAsync(counts + nxt, 0, 4, c->stream));
+                step(s2, nact, 0);
+                hipLaunchKernelGGL(k_modec_check, dim3((unsigned)((nact + 255) / 256)), dim3(256), 0, c->stream, s2, nact, o->ltol, it + 1);
+                first = false;
+            }
+            HIPCHK(hipMemcpyAsync(&nact, counts + (it & 1), 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return 0;
+    };
+    FZCHK(iterate(nullptr, (int)n, fast));
+    int namb = 0;
+    if (fast) {
+        HIPCHK(hipMemcpyAsync(&namb, counts + 3, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (namb > 0) {
+            // objects whose error came within rounding of ltol: once more from the start, IEEE divisions (their state planes are
+            // simply overwritten; the list lives behind the two active lists)
+            HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
+            FZCHK(iterate(st.amb, namb, false));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(&it_max, counts + 2, 4, hipMemcpyDeviceToHost, c->stream));      // iterations the slowest object took, minus one
     HIPCHK(hipStreamSynchronize(c->stream));
-    ++it;
-    c->tm.n_modec += it;             // iterations of the slowest object of the chunk (+1 per timed scope: the initial pass)
+    ++it_max;
+    c->tm.n_modec += it_max;         // iterations of the slowest object of the chunk (+1 per timed scope: the initial pass)
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -152,10 +215,10 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
 int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const int64_t* nbr, const int64_t* nnb, int W) {
     SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
 #if FZ_EXACT_BT
-    return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o, sub) : run_modec<FZ_BT, true>(c, n, o, sub);
+    return var == VAR_FAST ? run_modec<FZ_BT, false>(c, n, o, sub, true) : run_modec<FZ_BT, true>(c, n, o, sub, false);
 #else
     (void)var;
-    return run_modec<FZ_BT, true>(c, n, o, sub);
+    return run_modec<FZ_BT, true>(c, n, o, sub, false);
 #endif
 }
 

@@ -12,6 +12,14 @@
 // reproduces the reference's per-object iteration count exactly.  The solve keeps
 // NumPy's operation order (the library is built with -ffp-contract=off) so that the
 // iterates, and therefore the stop decision, track the reference to the last ulps.
+//
+// FAST solve (mask-free tame data): the eleven IEEE divisions of a solve (~12 instructions each, 40 % of it) become one
+// Newton-refined reciprocal per band (and one for the shape) that the three quotients of the band share.  The iterates then
+// differ from the IEEE ones in the last ulps -- eleven orders below ltol -- which can only change an object's iteration count if
+// its max |dlnl| lands within rounding of ltol.  That case is DETECTED, not assumed away: every model's error e_j carries a
+// bound d_j = 256 ulp (|lnl_new| + |lnl_old|) on what the two arithmetics can differ by, the step kernel reduces BOTH
+// max_j (e_j - d_j) and max_j (e_j + d_j) per object, and an object for which ltol falls between the two at any iteration is
+// flagged and re-run from the start with the IEEE solve.  Every other object provably takes the reference's iteration count.
 #pragma once
 #include "fz_device.h"
 
@@ -22,13 +30,17 @@ struct ModeCState {
     double* l;    // Gaussian lnl    (Nc,M)
     double* c;    // chi2            (Nc,M)
     double* sh;   // shape           (Nc,M)
-    unsigned long long* err;   // (Nc) max |dlnl| as ordered bits
+    unsigned long long* err;   // (Nc) max |dlnl| as ordered bits (FAST solve: max of the lower bounds |dlnl| - d)
+    unsigned long long* errhi; // FAST solve: (Nc) max of the upper bounds |dlnl| + d
     int* firstnan;             // (Nc) |dlnl[0]| is NaN
     const int* list;           // objects this launch advances (nullptr: all Nc), written by the last check
     int* list_next;            // objects that go on (filled by k_modec_check)
     int* nactive;              // (1) length of list_next
     const int* ncur;           // (1) length of `list` on the device (nullptr: Nc): the host launches for an upper bound
     int* last_iter;            // (1) highest iteration after which some object still went on
+    int* amb;                  // FAST solve: objects whose error came within rounding of ltol (list), may be nullptr
+    int* namb;                 // (1) their number
+    int* ambflag;              // (Nc) already listed
 };
 
 // Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
@@ -44,8 +56,41 @@ struct ModeC {
 
     // one solve of (scale, chi2, lnl) for variance var_b = xe2_b + (s_prev*ye_b)^2;
     // s_prev = 1 gives the initial pass of pdf.py:171-194.
+    template <bool FAST = false>
     __device__ __forceinline__ void solve(int64_t i, int64_t j, double sprev, double& s, double& lnl,
                                           double& chi2, double& shape, int& ndim) const {
+        if constexpr (FAST && !MASKED) {
+            if (sub.nbr) j = sub.nbr[i * sub.W + j];
+            ndim = nband;
+            double rv[BT], y[BT], x[BT];
+            double inter = 0.0; shape = 0.0;
+            double vprod = 1.0; int vexp = 0;
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                // uniform base + 32-bit lane offset (the saddr form of the load): per-(band, model) 64-bit addresses, hoisted out of
+                // the iteration loop by the compiler, spilled the persistent kernel's state
+                const uint32_t jo = (uint32_t)j;
+                y[b] = (mv.y + (int64_t)b * mv.Mp)[jo];
+                x[b] = ov.x[i * BT + b];
+                const double sye = sprev * (mv.ye + (int64_t)b * mv.Mp)[jo];
+                const double var = fma(sye, sye, ov.v[i * BT + b]);          // xe^2 + (s*ye)^2
+                rv[b] = rcp_nr<2>(var);
+                const double yr = y[b] * rv[b];
+                inter = fma(yr, x[b], inter);
+                shape = fma(yr, y[b], shape);
+                int e; vprod *= frexp(var, &e); vexp += e;
+            }
+            s = inter * rcp_nr<2>(shape);
+            chi2 = 0.0;
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                const double d = fma(-s, y[b], x[b]);
+                chi2 = fma(d * d, rv[b], chi2);
+            }
+            const double slog = log_pos(vprod, global_tabs()) + (double)vexp * FZ_LN2;
+            lnl = -0.5 * chi2 - 0.5 * ((double)ndim * FZ_LN2PI + slog);
+            return;
+        }
         if (sub.nbr) j = sub.nbr[i * sub.W + j];
         uint32_t jb = MASKED ? (ov.bits[i] & mv.bits[j]) : 0xffffffffu;
         ndim = MASKED ? __popc(jb) : nband;
@@ -79,7 +124,7 @@ struct ModeC {
     }
 };
 
-template <class MC>
+template <class MC, bool FAST = false>
 __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_t Nc, int64_t M, int init) {
     const int64_t tiles = (M + 255) / 256;
     const int64_t slot = blockIdx.x / tiles;             // Nc = number of objects of this launch (an upper bound when st.ncur is set)
@@ -87,31 +132,136 @@ __global__ __launch_bounds__(256) void k_modec_step(MC mc, ModeCState st, int64_
     const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
     const int64_t j = (blockIdx.x % tiles) * 256 + threadIdx.x;
     const bool valid = j < M && (!mc.sub.nnb || j < mc.sub.nnb[i]);
-    double e = 0.0;
+    double e = 0.0, eh = 0.0;
     if (valid) {
         const int64_t k = i * M + j;
         double s, l, c, sh; int nd;
         if (init) {
-            mc.solve(i, j, 1.0, s, l, c, sh, nd);
+            mc.template solve<FAST>(i, j, 1.0, s, l, c, sh, nd);
         } else {
             const double lold = st.l[k];
-            mc.solve(i, j, st.s[k], s, l, c, sh, nd);
+            mc.template solve<FAST>(i, j, st.s[k], s, l, c, sh, nd);
             e = fabs(l - lold);
             if (j == 0 && e != e) st.firstnan[i] = 1;
+            if (FAST) {                                     // what the IEEE iterates could differ by: both ends of the interval
+                const double dl = 2.9e-14 * (fabs(l) + fabs(lold));
+                eh = e + dl; e = fmax(e - dl, 0.0);
+            }
         }
         st.s[k] = s; st.l[k] = l; st.c[k] = c; st.sh[k] = sh;
     }
     if (init) return;
     // block max, NaNs dropped (a > b is false for NaN)
     if (!(e == e)) e = 0.0;
+    if (!(eh == eh)) eh = 0.0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) e = fmax(e, __shfl_xor(e, o, 64));
-    __shared__ double red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    for (int o = 32; o > 0; o >>= 1) { e = fmax(e, __shfl_xor(e, o, 64)); if (FAST) eh = fmax(eh, __shfl_xor(eh, o, 64)); }
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[4 + (threadIdx.x >> 6)] = eh; }
     __syncthreads();
     if (threadIdx.x == 0) {
         e = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         atomicMax(&st.err[i], (unsigned long long)__double_as_longlong(e));   // e >= 0: bit order == value order
+        if (FAST) {
+            eh = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+            atomicMax(&st.errhi[i], (unsigned long long)__double_as_longlong(eh));
+        }
+    }
+}
+
+// ---- the whole fixed point of an object inside ONE block (M <= FZ_MCP_MAXM models) ----
+// The plane kernels above move 48 B of state per (object, model, iteration) through HBM -- 290 GB on the 2e4 x 1e4 benchmark:
+// and one launch pair per iteration.  Here a block of T threads owns an object for all its iterations: thread t
+// keeps the scale and ln-like of models t, t + T, ... in registers, the previous scale of every model sits in LDS (the final
+// chi2 / shape are functions of it: they are recomputed once after the stop instead of being carried), the stop rule is a
+// block reduction, and nothing but the model records (L2-resident) is read per iteration.  Same arithmetic, same stop rule
+// (builtin-max NaN semantics, FAST solve with interval detection).
+// Blocks take objects from a grid-stride loop, so one object that needs hundreds of iterations delays nobody.
+#define FZ_MCP_MAXM 16384                                // (LDS: 8 B per model)
+// FAST: the reciprocal-based solve; an object found ambiguous (ltol inside the interval of its error) is listed in st.amb and
+// left unfinished: the host runs the IEEE instantiation over that list.  MPT: models per thread (register arrays: 2 MPT doubles).
+// T x MPT: threads per block x models per thread.  The solve itself holds ~90 VGPRs, the state 4 per model: (1024, <= 4) at
+// 128 VGPRs, (768, 14) at 168 -- the 1e4-model benchmark -- and (512, 32) at 256 are the spill-free shapes.
+template <class MC, bool FAST, int FZ_MCP_T, int MPT>
+__global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st, int64_t Nc, int M, double ltol, int max_iter, int* status) {
+    extern __shared__ double s_old[];                     // [M] the scale every model's last solve started from
+    __shared__ double red[2][FZ_MCP_T / 64];
+    __shared__ int s_flag[2];
+    const int tid = threadIdx.x;
+    for (int64_t slot = blockIdx.x; slot < Nc; slot += gridDim.x) {
+        const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
+        const int Mi = mc.sub.nnb ? (int)(mc.sub.nnb[i] < M ? mc.sub.nnb[i] : M) : M;
+        double sc[MPT], ll[MPT];
+#pragma unroll
+        for (int m = 0; m < MPT; ++m) {
+            int j = tid + m * FZ_MCP_T;
+            asm volatile("" : "+v"(j));                  // re-formed per use: every (model, array) address kept live across the iteration loop spills the state
+            sc[m] = 1.0; ll[m] = 0.0;
+            if (j < Mi) {
+                double c, sh; int nd;
+                mc.template solve<FAST>(i, j, 1.0, sc[m], ll[m], c, sh, nd);
+                s_old[j] = 1.0;
+            }
+        }
+        int iters = 0, f = 0;
+        while (true) {
+            double e = 0.0, eh = 0.0; int fnan = 0;
+#pragma unroll
+            for (int m = 0; m < MPT; ++m) {
+                int j = tid + m * FZ_MCP_T;
+            asm volatile("" : "+v"(j));                  // re-formed per use: every (model, array) address kept live across the iteration loop spills the state
+                if (j < Mi) {
+                    double sn, ln, c, sh; int nd;
+                    mc.template solve<FAST>(i, j, sc[m], sn, ln, c, sh, nd);
+                    double ej = fabs(ln - ll[m]);
+                    if (j == 0 && ej != ej) fnan = 1;
+                    double ehj = ej;
+                    if (FAST) { const double dl = 2.9e-14 * (fabs(ln) + fabs(ll[m])); ehj = ej + dl; ej = fmax(ej - dl, 0.0); }
+                    if (ej == ej) e = fmax(e, ej);         // NaNs dropped (builtin max)
+                    if (ehj == ehj) eh = fmax(eh, ehj);
+                    s_old[j] = sc[m]; sc[m] = sn; ll[m] = ln;
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one solve at a time: interleaving MPT of them spills the state arrays
+            }
+            ++iters;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { e = fmax(e, __shfl_xor(e, o, 64)); eh = fmax(eh, __shfl_xor(eh, o, 64)); }
+            if ((tid & 63) == 0) { red[0][tid >> 6] = e; red[1][tid >> 6] = eh; }
+            if (tid == 0) s_flag[1] = fnan;
+            __syncthreads();
+            if (tid == 0) {
+                double E = 0.0, EH = 0.0;
+                for (int w = 0; w < FZ_MCP_T / 64; ++w) { E = fmax(E, red[0][w]); EH = fmax(EH, red[1][w]); }
+                const bool fn = s_flag[1] != 0;
+                int g = (!fn && E > ltol) ? 1 : 0;                               // `while lerr > ltol`
+                if (FAST && !fn && E <= ltol && EH > ltol) g = 2;                // ltol inside the interval: the IEEE iterates decide
+                if (g == 1 && iters >= max_iter) g = 3;
+                s_flag[0] = g;
+            }
+            __syncthreads();
+            f = s_flag[0];
+            __syncthreads();
+            if (f != 1) break;
+        }
+        if (f == 3 && tid == 0) atomicMax(status, 1);
+        if (f == 2) {                                     // left to the IEEE instantiation
+            if (tid == 0) st.amb[atomicAdd(st.namb, 1)] = (int)i;
+            continue;
+        }
+        // the last solve once more, from the scale it started from: its chi2 and shape (scale and ln-like are the registers')
+#pragma unroll
+        for (int m = 0; m < MPT; ++m) {
+            int j = tid + m * FZ_MCP_T;
+            asm volatile("" : "+v"(j));                  // re-formed per use: every (model, array) address kept live across the iteration loop spills the state
+            if (j < Mi) {
+                double sn, ln, c, sh; int nd;
+                mc.template solve<FAST>(i, j, s_old[j], sn, ln, c, sh, nd);
+                const int64_t k = i * M + j;
+                st.s[k] = sn; st.l[k] = ln; st.c[k] = c; st.sh[k] = sh;
+            }
+        }
+        if (tid == 0) atomicMax(st.last_iter, iters);
+        __syncthreads();
     }
 }
 
@@ -122,6 +272,12 @@ static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol, int
     const double e = __longlong_as_double((long long)st.err[i]);
     const bool go = !st.firstnan[i] && (e > ltol);       // `while lerr > ltol`
     st.err[i] = 0ull;
+    // FAST solve: ltol between the two bounds of the object's error -- the IEEE iterates could decide the other way
+    if (st.amb) {
+        const double ehi = __longlong_as_double((long long)st.errhi[i]);
+        st.errhi[i] = 0ull;
+        if (!st.firstnan[i] && e <= ltol && ehi > ltol && !st.ambflag[i]) { st.ambflag[i] = 1; st.amb[atomicAdd(st.namb, 1)] = i; }
+    }
     if (go) { st.list_next[atomicAdd(st.nactive, 1)] = i; atomicMax(st.last_iter, iter); }
 }
 

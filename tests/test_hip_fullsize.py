@@ -186,3 +186,35 @@ class _Slice(object):
     def normal(self, loc, scale):
         assert np.shape(loc) == self.draws.shape
         return self.draws
+
+
+def test_config4_knn_at_its_stated_million_objects():
+    """BASELINE configs[3] at its stated size: 1e6 objects x 1e5 models, K = 25, k = 20 (knn.py:722-874), ``save_fits=False``
+    (no fit_* / neighbour attributes are kept, as in the reference).  Size-independent properties on every row --
+    normalised finite non-negative PDFs, ln-max <= ln-evidence <= ln-max + ln(K k) -- and the first and last 2 000 objects
+    against separate 2 000-object calls fed the same Monte-Carlo draws (a k-NN object's result does not depend on its
+    batch: same neighbours, so the same PDFs to rounding and bit-identical ln-max)."""
+    from frankenz_amd import NearestNeighbors
+    n, m = 1000000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
+    Ye = 0.03 * Y + 0.1 * SDSS_SIGMA
+    d, od = dicts()
+    fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9))
+    nn = NearestNeighbors(Y, Ye, Ym, K=25, feature_map='luptitude', fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(2), k=20, label_dict=d,
+                                 return_gof=True, verbose=False, save_fits=False)
+    W = 500
+    assert p.shape == (n, 701)
+    for lo in range(0, n, 100000):                                            # blockwise: keeps the temporaries small
+        sl = slice(lo, lo + 100000)
+        pb = p[sl]
+        assert np.isfinite(pb).all() and pb.min() >= 0
+        np.testing.assert_allclose(pb.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+        assert np.all(le[sl] >= lm[sl] - 1e-12) and np.all(le[sl] <= lm[sl] + np.log(W) + 1e-9)
+    for sub in (slice(0, 2000), slice(n - 2000, n)):
+        nn2 = NearestNeighbors(Y, Ye, Ym, K=25, feature_map='luptitude', fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
+        p2, (lm2, le2) = nn2.fit_predict(X[sub].copy(), Xe[sub].copy(), Xm[sub].copy(), z, ze, rstate=_Slice(np.random.RandomState(2), X, Xe, sub),
+                                         k=20, label_dict=d, return_gof=True, verbose=False, save_fits=True)
+        assert nn2.Nneighbors.min() >= 20 and nn2.Nneighbors.max() <= W
+        np.testing.assert_allclose(p2, p[sub], rtol=1e-12, atol=1e-16); np.testing.assert_array_equal(lm2, lm[sub])
+        np.testing.assert_allclose(le2, le[sub], rtol=1e-13, atol=1e-13)

@@ -1,8 +1,9 @@
 #!/bin/bash
+# mode C: parity (golden G2 + the mode C parametrisations of the suite), then the bench line with the reciprocal-based and the IEEE solve
 export TMPDIR=/tmp
-export FZ_BENCH_NO_EXTRA=1
-O=gpurun_out
-mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/modec_stats -- python3 bench.py --mode C --model-err varying --nobj 20000 --nmodel 10000 --no-cpu --steps 2 --warmup 1 > $O/modec_stats.log 2>&1
-tail -1 $O/modec_stats.log | cut -c1-300
-f=$(ls -t $O/modec_stats/*/*kernel_stats.csv | head -1); head -8 $f | cut -c1-200
+python -m pytest tests -m gpu -x -q -k "mode_c or modec or g2 or cdf_threshold or g1_" 2>&1 | tail -3
+for cfg in "" "FZ_MODEC_IEEE=1" "FZ_MODEC_PLANES=1"; do
+  env $cfg python3 bench.py --mode C --model-err varying --nobj 20000 --nmodel 10000 --no-cpu --steps 2 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$cfg', '%.4g evals/s  %.2f ms/step  iterations %s' % (d['value'], d['ms_per_step'], d['roofline']['modec_iterations_per_step']))"
+done
