@@ -223,8 +223,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             const unsigned long long mask = __ballot(am);
             if (mask) {                                           // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
-                hs.namb[o] += __builtin_popcountll(mask);
+                const int np = __builtin_popcountll(mask);
+                // the list holds `cap` entries (the launcher sizes it well above what a well-fitted object needs, not at M): an
+                // object that would overflow it -- every model within the band of a poor best fit -- is handed to the exact sweep
+                if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
+                    if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                    hs.namb[o] += np;
+                } else hs.namb[o] = -1;                           // overflowed: nothing more is stored, the object goes to the sweep
             }
         };
         // settle the first (up to) 64 entries of object o's buffer with all lanes; what lies behind them moves to the front
@@ -305,8 +310,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             const unsigned long long mask = __ballot(am);
                             if (mask) {
                                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                                if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
-                                hs.namb[o] += __builtin_popcountll(mask);
+                                const int np = __builtin_popcountll(mask);
+                                if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
+                                    if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                                    hs.namb[o] += np;
+                                } else hs.namb[o] = -1;
                             }
                         }
                         if ((++hs.tick & 15) == 0) {
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 const float tm = EXACT ? 0.f : wave_maxf(hs.tmax[o]);
                 // no candidate at all, an evidence that is not a number, or a best weight so far below the mode
                 // that the fp32 remainder has lost terms (2^-126 / 2^-80: still 2^-46 below the best): the exact ln-space sweep decides
-                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f));
+                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f)) && hs.namb[o] >= 0;
                 // the ambiguous band, by the reference's own rule (pdf.py:591) with the exact maximum and evidence
                 const int na = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                 if (na > 0) {

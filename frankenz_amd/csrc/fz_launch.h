@@ -357,7 +357,12 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     bpc = std::max(1, bpc);
     const int64_t groups = (n + TW - 1) / TW;
     const int64_t need = (groups + NW - 1) / NW;
-    const size_t per_wave = (size_t)TW * M * sizeof(fz::Cand);        // the ambiguous lists can never overflow (cap = M); only what is used is touched
+    // the ambiguous lists: a thin band of the candidates when the best model fits well (~1 % of M on the benchmark).  Sized at
+    // M up to 131 072 models (can never overflow), M / 8 beyond (an object that overflows is re-run by the exact sweep): a
+    // 1e6-model set then keeps the whole chip busy inside the workspace budget
+    int64_t acap = (M <= 131072) ? M : std::max<int64_t>(131072, M / 8);
+    if (const char* e = getenv("FZ_HIST_AMBCAP")) acap = std::max<int64_t>(1, atoll(e));      // (tests: forces the overflow hand-back)
+    const size_t per_wave = (size_t)TW * acap * sizeof(fz::Cand);
     const int64_t fit = (int64_t)(c->ws_limit / (per_wave * NW));
     int64_t blocks = need;
     if (need > c->cu_count) {
@@ -375,7 +380,7 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
-                       (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M, lmap, levid, pdfs, c->omap, c->d_redo.as<int>());
+                       (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), acap, lmap, levid, pdfs, c->omap, c->d_redo.as<int>());
     {
         // sweep: the exact ln-space body over the objects handed back (count on the device)
         auto sweep = fz::k_fused<SRC, 1, SW, false, true>;

@@ -143,12 +143,15 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
     lm = torch.empty(rows, dtype=torch.float64, device=dev)
     le = torch.empty(rows, dtype=torch.float64, device=dev)
     extra = set(kwargs) - {"label_dict", "label_grid", "kde_kwargs", "lprob_kwargs", "lprob_func", "lprob_args", "kde_args",
-                           "return_gof", "save_fits", "verbose", "track_scale"}
+                           "return_gof", "save_fits", "verbose", "track_scale", "prepared"}
     if extra or kwargs.get("kde_args") or kwargs.get("lprob_args"):
         raise NotImplementedError("sharded_fit_predict (overlapped BruteForce path): unsupported arguments %s" % sorted(extra))
-    # models, dictionary, labels: on the device once, not once per round
-    prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
-                                      kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"))
+    # models, dictionary, labels: on the device once, not once per round -- and not at all when the caller hands in the
+    # handle of an earlier ``prepare_fit_predict`` (a driver that calls this function step after step)
+    prep = kwargs.get("prepared")
+    if prep is None:
+        prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
+                                          kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"))
     works, t_comp = [], 0.0
     sync()
     t_start = time.perf_counter()
@@ -187,6 +190,8 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
 def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_label_errs, gather='pdfs',
                         group=None, rstate=None, chunks=4, **kwargs):
     """``fitter.fit_predict`` (BruteForce or NearestNeighbors) on this rank's block of objects.
+    (``prepared=``: a handle from ``fitter.prepare_fit_predict(...)`` with the same labels and options -- the overlapped
+    BruteForce path then skips the uploads / content checks of models, dictionary and labels.)
 
     Returns ``(pdfs, (lmap, levid))``: the FULL arrays when ``gather='pdfs'``; the local
     block when ``gather`` is ``None``; ``(stack, (lmap_local, levid_local))`` with the

@@ -464,7 +464,8 @@ def test_band_constant_model_errors_take_the_hoisted_path(kw, errs, monkeypatch)
 @pytest.mark.parametrize('env', [{'FZ_HIST': '0', 'FZ_FUSED_CFG': '4,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,16'},
                                  {'FZ_HIST': '0', 'FZ_FUSED_CFG': '1,4'}, {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1'}, {'FZ_CHUNK': '5000'},
                                  {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1', 'FZ_FUSED_CFG': '2,16'}, {'FZ_HIST': '0'},
-                                 {'FZ_HIST_CFG': '2,8'}, {'FZ_HIST_NOSCRB': '1'}, {'FZ_NOLIST': '1'}, {'FZ_HIST': '0', 'FZ_NOLIST': '1'}])
+                                 {'FZ_HIST_CFG': '2,8'}, {'FZ_HIST_NOSCRB': '1'}, {'FZ_NOLIST': '1'}, {'FZ_HIST': '0', 'FZ_NOLIST': '1'},
+                                 {'FZ_HIST_AMBCAP': '3'}, {'FZ_HIST_AMBCAP': '3', 'FZ_NOLIST': '1'}])      # ambiguous lists of 3 entries: (nearly) every object overflows and is re-run by the exact sweep
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
     """every launch geometry / kernel body / chunking reachable through the diagnostic
     environment switches gives the same PDFs (summation order aside)."""
