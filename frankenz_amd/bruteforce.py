@@ -23,7 +23,7 @@ import sys
 import numpy as np
 
 from . import pdf as _pdf
-from .engine import HostObjects, get_engine, kde_opts, like_opts
+from .engine import HostObjects, get_engine, kde_opts, like_opts, merge_kde_args
 
 __all__ = ["BruteForce"]
 
@@ -298,8 +298,7 @@ class BruteForce():
     def predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, logwt=None,
                 kde_args=None, kde_kwargs=None, return_gof=False, verbose=True):
         """bruteforce.py:207-301."""
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if logwt is None:
             logwt = self.fit_lnprob
         if label_dict is None and label_grid is None:
@@ -326,8 +325,7 @@ class BruteForce():
     def _predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, logwt=None,
                  kde_args=None, kde_kwargs=None):
         """Generator twin (bruteforce.py:303-372): yields ``(pdf, (lmap, levid))``."""
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if logwt is None:
             logwt = self.fit_lnprob
         if label_dict is None and label_grid is None:
@@ -363,14 +361,12 @@ class BruteForce():
             if host is not None or save_fits and hasattr(data, "data_ptr"):
                 raise NotImplementedError("device tensors / `out=` need the built-in likelihood and save_fits=False "
                                           "(the fit_* planes are host arrays)")
-            if kde_args:
-                raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+            kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
             if label_dict is None and label_grid is None:
                 raise ValueError("`label_dict` or `label_grid` must be specified.")
             return self._fit_predict_into(data, data_err, data_mask, model_labels, model_label_errs, label_dict, label_grid,
                                           kde_kwargs, lprob_kwargs, prior, return_gof, track_scale, save_fits, out)
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
         if host is not None:
@@ -441,8 +437,7 @@ class BruteForce():
                      save_fits=True):
         """Generator twin (bruteforce.py:505-631): yields ``(pdf, (lmap, levid))``."""
         prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
         if host is not None:

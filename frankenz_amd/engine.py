@@ -28,6 +28,27 @@ def like_opts(lprob_kwargs, max_iter=0):
                     float(kw.get("ltol", 1e-4)), int(bool(kw.get("exact_evidence", False))), 0)
 
 
+def merge_kde_args(kde_args, kde_kwargs, use_dict):
+    """Positional ``kde_args`` of predict / fit_predict, as the reference hands them on (bruteforce.py:361-369):
+    ``gauss_kde_dict(label_dict, y_idx=.., y_std_idx=.., y_wt=wt, *kde_args, **kde_kwargs)`` -- up to two positionals land
+    on ``y`` / ``y_std``, which the function ignores when the indices are given (pdf.py:570-573), a third collides with
+    ``y_idx``; ``gauss_kde(labels, label_errs, grid, y_wt=wt, *kde_args, **kde_kwargs)`` -- the first positional is ``dx``,
+    a second collides with ``y_wt``.  Returns the keyword dict to use; raises the TypeError Python raises for the rest."""
+    kw = dict(kde_kwargs or {})
+    args = tuple(kde_args or ())
+    if use_dict:
+        if len(args) > 2:
+            raise TypeError("gauss_kde_dict() got multiple values for argument 'y_idx'")
+        return kw
+    if len(args) > 1:
+        raise TypeError("gauss_kde() got multiple values for argument 'y_wt'")
+    if len(args) == 1:
+        if 'dx' in kw:
+            raise TypeError("gauss_kde() got multiple values for argument 'dx'")
+        kw['dx'] = args[0]
+    return kw
+
+
 def kde_opts(kde_kwargs, normalize=True):
     """kde_kwargs of gauss_kde / gauss_kde_dict -> fz_kde_opts.  ``wt_thresh=None``
     with ``cdf_thresh=None`` means no thresholding (pdf.py:495-496, 578-579)."""

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import pdf as _pdf
 from .bruteforce import _check_lprob, _progress
-from .engine import HostObjects, _digest, get_engine, kde_opts, like_opts
+from .engine import HostObjects, _digest, get_engine, kde_opts, like_opts, merge_kde_args
 
 __all__ = ["NearestNeighbors"]
 
@@ -288,8 +288,7 @@ class NearestNeighbors():
     def predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, logwt=None,
                 kde_args=None, kde_kwargs=None, return_gof=False, verbose=True):
         """knn.py:390-486."""
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if logwt is None:
             logwt = self.fit_lnprob
         if label_dict is None and label_grid is None:
@@ -333,8 +332,7 @@ class NearestNeighbors():
                     return_gof=False, track_scale=False, verbose=True, save_fits=True):
         """knn.py:560-720."""
         prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
-        if kde_args:
-            raise NotImplementedError("positional `kde_args` are not supported; use `kde_kwargs`")
+        kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if label_dict is None and label_grid is None:
             raise ValueError("`label_dict` or `label_grid` must be specified.")
         if rstate is None:

@@ -145,3 +145,17 @@ def test_network_lists_from_a_plane():
         for j in range(Nn):
             np.testing.assert_allclose(r.nodes_logwts[j], lw[j], rtol=1e-13, atol=1e-13)
             np.testing.assert_allclose(r.nodes_scales[j], ss[j], rtol=0, atol=0)
+
+
+def test_kde_args_follow_python_call_semantics():
+    """bruteforce.py:361-369 hands ``*kde_args`` on behind keyword arguments: what Python makes of that"""
+    from frankenz_amd.engine import merge_kde_args
+    assert merge_kde_args(None, {'wt_thresh': 0.1}, True) == {'wt_thresh': 0.1}
+    assert merge_kde_args((1, 2), None, True) == {}                    # land on y / y_std, ignored next to y_idx / y_std_idx (pdf.py:570-573)
+    with pytest.raises(TypeError, match="y_idx"):
+        merge_kde_args((1, 2, 3), None, True)
+    assert merge_kde_args((0.02,), {'sig_thresh': 3.}, False) == {'dx': 0.02, 'sig_thresh': 3.}
+    with pytest.raises(TypeError, match="'dx'"):
+        merge_kde_args((0.02,), {'dx': 0.01}, False)
+    with pytest.raises(TypeError, match="y_wt"):
+        merge_kde_args((0.02, None), None, False)

@@ -866,3 +866,53 @@ def test_exact_evidence_option_is_fp64_everywhere(case, monkeypatch):
         close(leb[sel], rle, **EVID64); close(lea[sel], rle, **EVID)
         np.testing.assert_array_equal(lma, lmb); close(pa, pb, rtol=1e-10, atol=1e-16)
         close(pb[sel], rp, rtol=1e-8, atol=1e-14)
+
+
+def test_positional_kde_args_reach_the_kde_as_in_the_reference():
+    """``kde_args`` (bruteforce.py:207-209, 361-369): the grid KDE takes its first positional as ``dx``; the dictionary KDE
+    ignores up to two (they land on ``y`` / ``y_std`` next to the given indices)."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(31)
+    M, N, B = 400, 12, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.3 * rs.randn(N, B); Xe = np.full((N, B), 0.3); Xm = np.ones((N, B))
+    z = rs.uniform(0.5, 5.5, M); ze = rs.uniform(0.02, 0.1, M)
+    grid = np.arange(0, 7 + 1e-5, .01)
+    bf = BruteForce(Y, Ye, Ym)
+    a = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_grid=grid, kde_args=(0.02,), save_fits=False, verbose=False)
+    b = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_grid=grid, kde_kwargs={'dx': 0.02}, save_fits=False, verbose=False)
+    np.testing.assert_array_equal(a, b)
+    c = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, kde_args=(None, None), save_fits=False, verbose=False)
+    e = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, save_fits=False, verbose=False)
+    np.testing.assert_array_equal(c, e)
+    with pytest.raises(TypeError):
+        bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_grid=grid, kde_args=(0.02, None), save_fits=False, verbose=False)
+
+
+def test_uploads_are_remembered_by_content_and_in_place_edits_are_seen():
+    """The engine skips uploads of what the device already holds, keyed on a content hash -- the reference keeps REFERENCES to
+    the caller's model arrays (bruteforce.py:54-56), so an in-place edit between two calls must change the answer."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(77)
+    M, N, B = 900, 40, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.1 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + 0.3 * rs.randn(N, B); Xe = np.full((N, B), 0.3); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, return_gof=True, save_fits=False, verbose=False)
+    p0, (lm0, le0) = run()
+    eng = get_engine()
+    k_models, k_labels = eng._models_key, eng._labels_key
+    p1, (lm1, le1) = run()
+    assert eng._models_key == k_models and eng._labels_key == k_labels            # nothing changed: nothing re-sent
+    np.testing.assert_array_equal(lm1, lm0)
+    Y[::7] *= 1.5                                                               # in place: same array object, new content
+    z[::5] = 6.0 - z[::5]
+    p2, (lm2, le2) = run()
+    assert eng._models_key != k_models and eng._labels_key != k_labels
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od)
+    close(p2, rp, rtol=1e-8, atol=1e-14); close(lm2, rlm, rtol=1e-10); close(le2, rle, **EVID)
+    assert np.abs(p2 - p0).max() > 1e-3
