@@ -395,7 +395,7 @@ def main():
                               "pdfs_normalised": ok, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "BruteForce.predict(logwt=fit_lnprob): %d x %d plane -> %d PDFs" % (N, M, N)},
                               "kernel_ms_per_step": {k: tm["ms_" + k] / args.steps for k in ("fused", "stats", "kde", "other")},
-                              "roofline": {"bound": "hbm", "kernel": "k_plane_fused" if tm["ms_fused"] > tm["ms_stats"] + tm["ms_kde"] else "k_stats + k_kde",
+                              "roofline": {"bound": "hbm", "kernel": eng.last_form(),
                                            "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                            "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))

@@ -5,6 +5,7 @@
 #include "fz_ol.h"
 #include "fz_nolist.h"
 #include "fz_hist.h"
+#include "fz_plane.h"
 
 inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
     using namespace fz;
@@ -71,6 +72,43 @@ int fz_launch_kde(fz_ctx* c, const SRC& src, int64_t n, int64_t M, int linear, c
     return fz_launch_kde_tw<SRC, 1>(c, src, kv, 1, n, M, linear, lmap, levid, ko, pdfs);
 }
 
+// register-resident rows (fz_plane.h); +1 = not applicable
+template <int NW, int E2>
+int fz_launch_plane_rows_g(fz_ctx* c, const double* plane, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                           double* lmap, double* levid, double* pdfs) {
+    auto kern = fz::k_plane_rows<NW, E2>;
+    constexpr size_t NT = (size_t)NW * 64;
+    // exp table | two histogram rows | 1 / mass | exchange words | flags | label indices of the lanes' columns | parked ties
+    const size_t lds = ((size_t)FZ_HEXP_K + 3 * (size_t)kv.acc_stride + 3 * NW + 2) * 8 + 2 * NW * 4 + NT * E2 * 4 + NT * 12;
+    if (lds > 160 * 1024) return 1;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, lds));
+    const int64_t blocks = std::min<int64_t>(n, (int64_t)std::max(1, bpc) * c->cu_count);
+    FZCHK(c->d_kv.ensure(sizeof(fz::KdeView)));
+    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
+    Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, plane, M, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
+                       (int)M, ko->wt_thresh, ko->normalize, lmap, levid, pdfs);
+    HIPCHK(hipGetLastError());
+    c->last_form = "k_plane_rows";
+    return 0;
+}
+inline int fz_launch_plane_rows(fz_ctx* c, const double* plane, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
+                                double* lmap, double* levid, double* pdfs) {
+    const int64_t G = kv.G, w2 = 2 * (int64_t)kv.w0;
+    if (w2 >= 128 || G + w2 > 65535 || G + w2 > kv.acc_stride || G > 8 * 128) return 1;
+    int nw = 8, e2 = 10;
+    if (const char* e = getenv("FZ_PLANE_ROWS_CFG")) sscanf(e, "%d,%d", &nw, &e2);
+    else if (M > 8 * 64 * 2 * 10) { nw = 16; e2 = 10; }
+    if (M > (int64_t)nw * 64 * 2 * e2) return 1;
+    if (nw == 8 && e2 == 10) return fz_launch_plane_rows_g<8, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
+    if (nw == 16 && e2 == 5) return fz_launch_plane_rows_g<16, 5>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
+    if (nw == 16 && e2 == 10) return fz_launch_plane_rows_g<16, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
+    return 1;
+}
+
 // predict from a stored ln-weight plane: one pass (k_plane_fused) when its candidate lists fit the
 // workspace budget, else / for linear weights / FZ_PLANE_TWOPASS=1 the two-pass kernels
 inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, int64_t M, int linear,
@@ -89,6 +127,12 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
                             : (ho ? k_plane_fused<NW, 1, true, true> : k_plane_fused<NW, 1, false, true>))
                     : (vec2 ? (ho ? k_plane_fused<NW, 2, true, false> : k_plane_fused<NW, 2, false, false>)
                             : (ho ? k_plane_fused<NW, 1, true, false> : k_plane_fused<NW, 1, false, false>));
+    // rows that fit one block's registers: exact maximum first, then fp64 weights straight into the LDS histogram (fz_plane.h)
+    if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && vec2 && ho && kv.normtab && ko->wt_thresh >= 0.0 &&
+        (!getenv("FZ_PLANE_ROWS") || atoi(getenv("FZ_PLANE_ROWS")) != 0)) {
+        const int r = fz_launch_plane_rows(c, plane, kv, n, M, ko, lmap, levid, pdfs);
+        if (r <= 0) return r;
+    }
     int64_t blocks = 0;
     if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -101,6 +145,7 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
         if (blocks > 0 && c->d_cand.ensure((size_t)blocks * NW * M * sizeof(Cand)) != 0) blocks = 0;
     }
     if (blocks <= 0) {
+        c->last_form = "k_stats + k_kde";
         FZCHK(fz_launch_stats(c, ps, n, M, linear, lmap, levid));
         return fz_launch_kde(c, ps, n, M, linear, lmap, levid, ko, pdfs);
     }
@@ -111,6 +156,7 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, plane, M, c->d_kv.as<KdeView>(),
                        kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<Cand>(), M, lmap, levid, pdfs);
     HIPCHK(hipGetLastError());
+    c->last_form = "k_plane_fused";
     return 0;
 }
 

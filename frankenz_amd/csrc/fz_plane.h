@@ -1,0 +1,296 @@
+// k_plane_rows: predict() from a stored (N, M) ln-weight plane when a row fits the REGISTERS of one block
+// (BruteForce._predict, bruteforce.py:303-372 -> pdf.py:585-622 with a single dictionary kernel).
+//
+// k_plane_fused streams a row once but cannot know the row's maximum while it does, so every entry within the weight
+// threshold of the RUNNING best -- one in ten on the benchmark plane -- is written to a per-wave list in HBM and walked
+// twice afterwards (PMC, profiles/r3_v2_pmc_predict_before.txt: one 16-B store per 64 entries read, 2.7 GB of list
+// traffic beside the 8 GB plane, 44 vector instructions per entry).  Rows up to NW * 64 * 2 * E2 entries long (10 240 at
+// the (8, 10) shape: the benchmark's 1e4 models) need none of that: the block loads the whole row into registers (E2
+// 16-byte non-temporal loads per lane, all in flight together), takes the exact maximum (one LDS exchange), and then
+// weighs every entry in fp64 against it: w = exp(l - max), the evidence sum, and -- the reference's rule
+// wt > wt_thresh * max(wt) (pdf.py:591) is w > wt_thresh in these units -- one ds_add_f64 into the block's histogram at
+// the entry's label index for the stacked ones.  A lane always holds the same model columns, so their label indices sit
+// in registers for the life of the block: no gathers.  Entries within 1e-9 of the threshold are decided by the
+// reference's own expression once the evidence is known (they stay in registers until then).  The next row's loads are
+// issued before the convolution of the current one, which touches LDS and registers only (kernel taps in two registers
+// per wave, kernel masses staged in LDS), so they fly while the PDF is formed.  Everything is fp64: there is no fp32
+// remainder in the evidence and no list in HBM; traffic is the plane once and the PDFs once.
+#pragma once
+#include "fz_hist.h"
+
+namespace fz {
+
+// wave-wide sum / maximum of a double through the DPP network (no LDS pipe: the shuffles of wave_sum / wave_max take six
+// dependent ds_bpermute round trips); the result is wave-uniform, in scalar registers
+__device__ __forceinline__ double dpp_shuffle_d(double v, int ctrl_quad1, int ctrl_quad2, int which) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (which == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }
+    else if (which == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    else if (which == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); }
+    (void)ctrl_quad1; (void)ctrl_quad2;
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double plane_readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += dpp_shuffle_d(v, 0, 0, k);          // every lane: the sum of its row of 16
+    return (plane_readlane_d(v, 0) + plane_readlane_d(v, 16)) + (plane_readlane_d(v, 32) + plane_readlane_d(v, 48));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {             // nan operands are skipped (v_max_f64)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v = vmax_raw(v, dpp_shuffle_d(v, 0, 0, k));
+    return vmax_raw(vmax_raw(plane_readlane_d(v, 0), plane_readlane_d(v, 16)), vmax_raw(plane_readlane_d(v, 32), plane_readlane_d(v, 48)));
+}
+
+// ln(x) for x in [1, 1e300] without tables in memory and without a constant pool (libm's log keeps polynomial constants in
+// registers across the object loop: they spill, and the reload waits for the row in flight): v_log_f32 gives y to 1e-7, then
+// ln x = y + ln(x e^-y) = y + d - d^2 / 2 with d = x e^-y - 1 (|d| < 2e-7: the cubic term is 3e-21); e^-y from the LDS table
+__device__ __forceinline__ double log_by_exp(double x, const double* __restrict__ s_exp) {
+    const double y = (double)(__builtin_amdgcn_logf((float)x) * 0.69314718f);
+    const double d = fma(x, exp_small_tab(-y, s_exp), -1.0);
+    return y + fma(-0.5 * d, d, d);
+}
+
+// exp(x) for x <= 0 (or nan -> e^-700): exp_small_tab without the upper clamp and with the degree-4 polynomial
+// (|r| <= ln2 / 512: the dropped term r^5 / 120 is below 4e-17)
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ tab) {
+    const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
+    x = vmax_raw(x, -700.0);
+    const double d = fma(x, 369.3299304675746, MAGIC);           // 256 / ln 2
+    const double r = fma(d - MAGIC, -0.0027076061740622863, x);  // ln 2 / 256
+    const int n = __double2loint(d);
+    const double t = tab[n & (FZ_HEXP_K - 1)];
+    double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = t * p;                                      // in [1,2)
+    return __hiloint2double(__double2hiint(v) + ((n >> 8) << 20), __double2loint(v));
+}
+
+template <int NW, int E2>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plane_rows(const double* __restrict__ plane, int64_t ld, const KdeView* __restrict__ kvp,
+                                                         int acc_stride, int64_t N, int M, double wt_thresh, int normalize,
+                                                         double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs) {
+    constexpr int NT = NW * 64, CAPA = NT;
+    extern __shared__ double smem[];
+    double* s_exp = smem;                               // [FZ_HEXP_K] 2^(k/256)
+    double* rowA = s_exp + FZ_HEXP_K;                   // [acc_stride] x 2: the histograms of this object and of the next one (padded by w0 on either side)
+    double* s_inv = rowA + 2 * acc_stride;              // [acc_stride] 1 / kernel mass per padded index
+    double* s_red = s_inv + acc_stride;                 // [3 NW + 2] per-wave maxima, sums, stacked sums; the late (ambiguous) stacked sum
+    int* s_flag = reinterpret_cast<int*>(s_red + 3 * NW + 2);   // [NW] bit 0: a nan in the wave's part, bit 1: the row's first entry is nan
+    int* s_amb = s_flag + NW;                               // [NW] word 0: entries within rounding of the threshold (count)
+    int* s_tag = s_amb + NW;                                // [NT E2] padded label indices of models 2 k, 2 k + 1 in the halves of word k
+    double* s_ambl = reinterpret_cast<double*>(s_tag + NT * E2);    // [CAPA] ln-weights within rounding of the threshold (decided once the evidence is known)
+    int* s_ambp = reinterpret_cast<int*>(s_ambl + CAPA);            // [CAPA] their histogram indices
+    // (each exchange array is written in one barrier interval and read in the next one only, so a wave that runs ahead into
+    //  the next object can never overwrite what a slower one still reads)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const KdeView kv = *kvp;
+    const int G = (int)kv.G, w0 = kv.w0, w2 = 2 * w0, GP = G + w2;
+    const FastTabs tb = global_tabs();
+    for (int k = tid; k < FZ_HEXP_K; k += NT) s_exp[k] = FZ_EXP_TAB[k * (FZ_EXP_K / FZ_HEXP_K)];
+    for (int k = tid; k < acc_stride; k += NT) { rowA[k] = 0.0; rowA[acc_stride + k] = 0.0; s_inv[k] = (k < GP) ? 1.0 / kv.normtab[k] : 1.0; }
+    if (tid == 0) { s_red[3 * NW] = 0.0; s_amb[0] = 0; }
+    // a lane holds the same model columns for every object -- entry e: models 2 (e NT + tid) and +1 -- so their label indices
+    // are staged once (LDS rather than registers: the row itself takes 4 E2 of them)
+    for (int k = tid; k < NT * E2; k += NT) {
+        const int j = 2 * k;
+        const int p0 = (j < M) ? kv.pos[j] + w0 : 0, p1 = (j + 1 < M) ? kv.pos[j + 1] + w0 : 0;
+        s_tag[k] = p0 | (p1 << 16);
+    }
+    // dictionary kernel taps across the wave (as in kde_finalize)
+    const double* kr = kv.kern + kv.koff0;
+    const double ka = (lane <= w2) ? kr[lane] : 0.0;
+    const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
+    const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
+    const double thr_hi = uniform_d(wt_thresh * (1.0 + 1e-9)), thr_lo = uniform_d(wt_thresh * (1.0 - 1e-9));     // wave-uniform values live in scalar registers
+    __syncthreads();
+
+    fz_d2 l[E2];
+    // Row loads by hand: scalar base (the row) + ONE lane offset per entry formed on the spot, so the E2 requests need no
+    // address registers beside the E2 x 4 they fill (the compiler's form: a 64-bit address pair and a branch per entry, and
+    // parts of the row spilled to scratch).  Lanes past the end of a short row re-read its last entry and are set to -inf when
+    // the data are used.  The compiler does not count these loads: row_wait() is the s_waitcnt, tied to every register of the row.
+    const int last2 = M / 2 - 1;
+    auto load_row = [&](int64_t i) {
+        const char* rb = reinterpret_cast<const char*>(plane + i * ld);
+        int t = tid;
+        asm volatile("" : "+v"(t));                                          // offsets formed here, per row (hoisted, the E2 of them spill)
+#pragma unroll
+        for (int e = 0; e < E2; ++e) {
+            const unsigned off = (unsigned)min(e * NT + t, last2) * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(l[e]) : "v"(off), "s"(rb) : "memory");
+        }
+    };
+    auto row_wait = [&]() {
+        static_assert(E2 == 5 || E2 == 10, "operand list below");
+        if constexpr (E2 == 10)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7]), "+v"(l[8]), "+v"(l[9]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]));
+#pragma unroll
+        for (int e = 0; e < E2; ++e)
+            if (2 * (e + 1) * NT > M) {                                      // wave-uniform: only the entries the row's end falls into (or past)
+                if (2 * (e * NT + tid) >= M) l[e] = fz_d2{-INFINITY, -INFINITY};
+            }
+    };
+    // the taps were loaded above and are first used inside the convolution: consumed here, so that the compiler's wait for
+    // them sits before the object loop and not in the tap loop, where it would also wait for the next row in flight
+    asm volatile("" :: "v"(kal), "v"(kah), "v"(kbl), "v"(kbh));
+    int64_t i = blockIdx.x;
+    if (i < N) load_row(i);
+    int par = 0;
+    for (; i < N; i += gridDim.x, par ^= 1) {
+        double* row = rowA + par * acc_stride;                               // this object's histogram (zero: cleared one object ago)
+        double* rowz = rowA + (par ^ 1) * acc_stride;                        // the previous object's: cleared below, once every wave is past its convolution
+        const int64_t inext = i + gridDim.x;
+        row_wait();
+        // ---- exact maximum (nan never becomes the best: v_max_f64 returns the other operand) ----
+        double m = -INFINITY;
+        bool an = false;
+#pragma unroll
+        for (int e = 0; e < E2; ++e) {
+            m = vmax_raw(m, l[e].x); m = vmax_raw(m, l[e].y);
+            an |= (l[e].x != l[e].x) | (l[e].y != l[e].y);
+        }
+        const bool fnl = (tid == 0) && (l[0].x != l[0].x);
+        m = wave_max_dpp(m);
+        const int wf = (__any(an) ? 1 : 0) | (__any(fnl) ? 2 : 0);
+        if (lane == 0) { s_red[wave] = m; s_flag[wave] = wf; }
+        __syncthreads();                                                     // (1)
+        {
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
+            for (int k = tz; k < GP; k += NT) rowz[k] = 0.0;
+        }
+        double mx = s_red[0];
+        int fl = s_flag[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { mx = vmax_raw(mx, s_red[w]); fl |= s_flag[w]; }
+        mx = uniform_d(mx);
+        fl = __builtin_amdgcn_readfirstlane(fl);
+        const bool anynan = fl & 1, firstnan = fl & 2;
+        const bool tame = (mx - mx == 0.0);                                  // a finite best
+        // ---- weights against the maximum, evidence sum, histogram ----
+        double s = 0.0, ssel = 0.0;
+        if (tame) {
+            int tt = tid;
+            asm volatile("" : "+v"(tt));
+            const int* tg = s_tag + tt;
+#pragma unroll
+            for (int e = 0; e < E2; ++e) {
+                const int pt = tg[e * NT];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const double lv = q ? l[e].y : l[e].x;
+                    const double w = exp_nonpos_tab(lv - mx, s_exp);        // -inf, nan and pad columns: 1e-304
+                    s += w;
+                    if (w >= thr_lo) {                                       // stacked, or within rounding of the threshold
+                        const int p = q ? (pt >> 16) : (pt & 0xffff);
+                        if (w > thr_hi) {
+                            ssel += w;
+                            unsafeAtomicAdd(&row[p], w * s_inv[p]);         // weight / kernel mass of the index (pdf.py:613-617)
+                        } else {                                             // (rare) parked until the evidence is known
+                            const int k = atomicAdd(&s_amb[0], 1);
+                            if (k < CAPA) { s_ambl[k] = lv; s_ambp[k] = p; }
+                            else if (w > wt_thresh) { unsafeAtomicAdd(&row[p], w * s_inv[p]); unsafeAtomicAdd(&s_red[3 * NW], w); }   // (beyond CAPA ties: the rule in these units)
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // two entries at a time (all E2 at once spill the row)
+            }
+        }
+        // ---- the row is used up: the next one is requested now, and everything below touches LDS and registers only ----
+        if (inext < N) load_row(inext);
+        s = wave_sum_dpp(s);
+        ssel = wave_sum_dpp(ssel);
+        if (lane == 0) { s_red[NW + wave] = s; s_red[2 * NW + wave] = ssel; }
+        __syncthreads();                                                     // (2)
+        double S = 0.0, T = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { S += s_red[NW + w]; T += s_red[2 * NW + w]; }
+        S = uniform_d(S); T = uniform_d(T);
+        const int namb = __builtin_amdgcn_readfirstlane(s_amb[0]);
+        const bool ok = !anynan && tame;                                     // a finite evidence: S >= 1 (the best entry itself)
+        if (namb) {                                                          // block-uniform, rare: the reference's own expression decides
+            if (ok) {
+                const double le = mx + log_by_exp(S, s_exp);
+                const double thr = wt_thresh * exp_neg(mx - le, tb);        // wt_thresh * max(wt)
+                for (int k = tid; k < min(namb, CAPA); k += NT) {
+                    const double lv = s_ambl[k];
+                    const int p = s_ambp[k];
+                    if (exp_neg(lv - le, tb) > thr) {                       // strict
+                        const double w = exp_nonpos_tab(lv - mx, s_exp);
+                        unsafeAtomicAdd(&row[p], w * s_inv[p]);
+                        unsafeAtomicAdd(&s_red[3 * NW], w);
+                    }
+                }
+            }
+            __syncthreads();
+            T += uniform_d(s_red[3 * NW]);
+            __syncthreads();
+            if (tid == 0) { s_red[3 * NW] = 0.0; s_amb[0] = 0; }
+        }
+        if (wave == 0) {                                                     // ln-evidence: one wave, no tables (a table load would wait for the row in flight)
+            double le;
+            if (anynan) le = (double)NAN;
+            else if (!tame) le = mx;                                         // +inf, or -inf for a row of -inf
+            else le = mx + log_by_exp(S, s_exp);
+            if (lane == 0) {
+                if (lmap) lmap[i] = firstnan ? (double)NAN : mx;             // builtin max: NaN only if first
+                if (levid) levid[i] = le;
+            }
+        }
+        // ---- PDF: convolve, normalise, write ----
+        double* out = pdfs + i * G;
+        if (!ok) {
+            int t0 = tid;
+            asm volatile("" : "+v"(t0));
+            for (int t = t0; t < G; t += NT) out[t] = NAN;
+        } else if (wave * 128 < G) {                                         // wave-uniform; G <= NW * 128 (launcher): one pass, two outputs per lane
+            int lo = lane;
+            asm volatile("" : "+v"(lo));                                     // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
+            const int t = wave * 128 + lo;
+            const bool one = t < G, two = t + 64 < G;
+            const double* r0 = row + (one ? t : 0);
+            const double* r1 = row + (two ? t + 64 : 0);
+            double v0 = 0.0, v1 = 0.0;
+            const int hs = w2 < 64 ? 0 : w2 - 63;
+            for (int h = 0; h < hs; ++h) {
+                const int q = w2 - h - 64;
+                const double tap = __hiloint2double(__builtin_amdgcn_readlane(kbh, q), __builtin_amdgcn_readlane(kbl, q));
+                v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
+            }
+            int h = hs;
+            for (; h + 3 <= w2; h += 4) {                                    // four taps' LDS reads in flight; the sums in the same order
+                double a[4], b[4], tp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = r0[h + u]; b[u] = r1[h + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = w2 - h - u;
+                    tp[u] = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v0 = fma(a[u], tp[u], v0); v1 = fma(b[u], tp[u], v1); }
+            }
+            for (; h <= w2; ++h) {
+                const int q = w2 - h;
+                const double tap = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
+                v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
+            }
+            // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
+            // (the taps that land on the grid) = the sum of the stacked weights -- known since barrier (2), no second reduction
+            const double scale = normalize ? 1.0 / T : 1.0 / S;
+            if (one) out[t] = v0 * scale;
+            if (two) out[t + 64] = v1 * scale;
+        }
+    }
+}
+
+}  // namespace fz
