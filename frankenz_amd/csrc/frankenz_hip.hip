@@ -159,6 +159,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     c->M = M; c->Mp = Mp; c->B = B; c->BT = BT;
     c->mc_rec0_valid = c->mc_rec1_valid = false;
     c->models_masked = (fl & 1) || (BT != B);
+    c->models_real_masked = (fl & 1) != 0;
     c->models_wild = (fl & 4) != 0;
     // band-constant model errors (zeros for a template grid, a common floor, the SURVEY 8d
     // configurations): xe^2 + ye^2 does not depend on the model, so it is formed once per object
@@ -813,7 +814,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
             // When the models themselves are unmasked, the (usually large) share of objects with
             // every band observed keeps the mask-free kernels: the chunk is split in two launches.
             bool done = false;
-            if (var == VAR_MASKED && !c->models_masked && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
+            if (var == VAR_MASKED && !c->models_real_masked && (c->BT == c->B || c->BT > 8) && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
                 FZCHK(c->d_omap.ensure((size_t)n * 8 + 64));
                 int* fast = c->d_omap.as<int>(); int* slow = fast + n; int* counts = slow + n;
                 HIPCHK(hipMemsetAsync(counts, 0, 8, c->stream));
@@ -825,7 +826,7 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
                 if (cnt[0] >= 1024 && cnt[1] > 0) {
                     OmapGuard og{c};
                     c->omap = fast;
-                    const int r1 = run_fitpredict(c, mode, VAR_FAST, o->dim_prior, cnt[0], ko, d_lm, d_le, d_pdf);
+                    const int r1 = run_fitpredict(c, mode, pick_var(c, 0), o->dim_prior, cnt[0], ko, d_lm, d_le, d_pdf);
                     if (r1 < 0) return r1;
                     c->omap = slow;
                     const int r2 = (r1 == 0) ? run_fitpredict(c, mode, VAR_MASKED, o->dim_prior, cnt[1], ko, d_lm, d_le, d_pdf) : 2;

@@ -71,7 +71,7 @@ struct fz_ctx {
 
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
-    bool models_masked = false, models_wild = false, models_err_const = false;
+    bool models_masked = false, models_real_masked = false, models_wild = false, models_err_const = false;
     DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1, d_ye2c;
     // kde dictionary (PDFDict)
     int64_t G = 0, D = 0;
@@ -203,7 +203,8 @@ inline int obj_vmode(const fz_ctx* c, int mode) {      // what k_prep_objects de
 // arithmetic variant of a chunk: see VAR_* in fz_device.h
 inline int pick_var(fz_ctx* c, int obj_flags) {
     if (c->models_wild || (obj_flags & 4)) return fz::VAR_SAFE;
-    if (c->models_masked || (obj_flags & 1)) return fz::VAR_MASKED;
+    if (c->models_real_masked || (obj_flags & 1)) return fz::VAR_MASKED;
+    if (c->BT != c->B) return c->BT > 8 ? fz::VAR_PAD : fz::VAR_MASKED;
     return fz::VAR_FAST;
 }
 

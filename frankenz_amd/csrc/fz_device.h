@@ -77,7 +77,9 @@ __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg
 //   1  masks present (or B padded up to BT), tame variances: per-band masked terms
 //      with Newton-refined reciprocals
 //   2  anything else (zero/huge/non-finite variances): IEEE division throughout
-enum { VAR_FAST = 0, VAR_MASKED = 1, VAR_SAFE = 2 };
+enum { VAR_FAST = 0, VAR_MASKED = 1, VAR_SAFE = 2,
+       VAR_PAD = 3 };    // host-side only: tame, no REAL band masked, but the band count is padded up to 16 / 32 -- the one-pass kernel runs its
+                         // mask-free form (pad bands are zeros and add nothing), every other kernel its masked variant
 
 template <int BT, int MODE, int VAR>
 struct Phot {

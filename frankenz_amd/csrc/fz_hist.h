@@ -74,17 +74,54 @@ __device__ __forceinline__ double hist_exactw(double c2, const FastTabs& tb) {
     constexpr double K = (double)WP;
     const double r = c2 * (1.0 / K);
     double pw = 1.0;
-    if constexpr ((WP >> 1) >= 1) pw = r;
-    if constexpr ((WP >> 1) >= 2) pw = pw * r;
-    if constexpr ((WP >> 1) >= 3) pw = pw * r;
+    if constexpr ((WP >> 1) <= 3) {
+        if constexpr ((WP >> 1) >= 1) pw = r;
+        if constexpr ((WP >> 1) >= 2) pw = pw * r;
+        if constexpr ((WP >> 1) >= 3) pw = pw * r;
+    } else {
+        // wide band sets (k up to 30): r^(k/2) by squaring
+        double base = r;
+#pragma unroll
+        for (int e = WP >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }
+    }
     if constexpr (WP & 1) {
         double y = __builtin_amdgcn_rsq(r);
         y = y * fma(-0.5 * r, y * y, 1.5);
         y = y * fma(-0.5 * r, y * y, 1.5);
         pw = pw * ((r > 0.0) ? r * y : 0.0);              // chi2 == 0 (self match): weight 0
     }
-    return pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+    const double w = pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+    // the exponential is clamped at e^-700, which a high power of a huge chi2 would lift back into range (r^15 reaches 1e300):
+    // beyond the clamp the weight is zero, as in the reference's exp
+    if constexpr ((WP >> 1) > 3) return (c2 < K + 1400.0) ? w : 0.0;
+    else return w;
 }
+
+// the same for a band count known at run time (wide sets padded up to 16 / 32 bands: the pad bands add nothing to chi2, the
+// power is that of the REAL band count): r^(k div 2) by squaring over the bits of a wave-uniform k
+template <bool SMALL = false>
+__device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTabs& tb) {
+    const double K = (double)wp;
+    const double r = c2 * rcp_nr<2>(K);
+    double pw = 1.0, base = r;
+    for (int e = wp >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }     // scalar loop
+    if (wp & 1) {
+        double y = __builtin_amdgcn_rsq(r);
+        y = y * fma(-0.5 * r, y * y, 1.5);
+        y = y * fma(-0.5 * r, y * y, 1.5);
+        pw = pw * ((r > 0.0) ? r * y : 0.0);
+    }
+    const double w = pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+    return (c2 < K + 1400.0) ? w : 0.0;
+}
+
+// models per LDS tile by record width: two tiles, the histograms and the candidate buffers share 160 KB
+template <class SRC>
+constexpr int hist_tile() { return SRC::RW <= 18 ? 256 : (SRC::RW <= 34 ? 128 : 64); }
+// wide records: the next step's model record is NOT requested ahead where a second copy of the record does not fit the
+// register file beside the object (16 bands with per-model errors or the closed-form screen, 32 bands)
+template <class SRC, bool SCRB>
+constexpr bool hist_prefetch() { return 2 * SRC::NB + 2 * SRC::RW + (SCRB ? 2 * SRC::NB : 0) <= 96; }
 
 // wave-wide maximum of a float without the LDS pipe: DPP within rows of 16 lanes, then the four row results through scalar
 // registers; the result is wave-uniform (lanes hold the same SGPR-fed value)
@@ -130,13 +167,16 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                                    double wt_thresh, int normalize, Cand* __restrict__ amb, int64_t cap,
                                                    double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs,
                                                    const int* __restrict__ omap, int* __restrict__ redo) {
-    constexpr int TILE = 256, RW = SRC::RW, TDR = RW * TILE, TD = TDR + TILE / 2, NT = NW * 64, OD = SRC::OBJ_DOUBLES;
+    constexpr int TILE = hist_tile<SRC>(), RW = SRC::RW, TDR = RW * TILE, TD = TDR + TILE / 2, NT = NW * 64, OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW, BT = SRC::NB;
-    constexpr double K = (double)WP;
+    // wide instantiations (16 / 32 bands) also serve the band counts padded up to them: the power of chi2 follows the REAL count
+    constexpr bool KRT = (BT > 8);
+    const int wpr = __builtin_amdgcn_readfirstlane(KRT ? src_.lp.nband - (SRC::LMODE == 2 ? 3 : 2) : WP);
+    const double K = KRT ? (double)wpr : (double)WP;
     constexpr int NOBJ = NW * TW;
     constexpr int CAP = 128, DTHR = CAP - 64;                             // ring entries per object; drain from DTHR pending entries on
     using tag_t = typename std::conditional<SCRB, int32_t, uint16_t>::type;   // label index (< 65536, checked by the launcher) or model number
-    static_assert(WP >= 1 && WP <= 6, "chi2^(1/2) ... chi2^3");
+    static_assert(WP >= 1 && WP <= 30, "chi2^(1/2) ... chi2^15");
     __shared__ __attribute__((aligned(16))) double tileA[TD];
     __shared__ __attribute__((aligned(16))) double tileB[TD];
     __shared__ __attribute__((aligned(16))) double s_c2[EXACT ? 2 : NOBJ * CAP];
@@ -174,7 +214,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     const float T0 = (float)(-0.5 * K * log2(K));
     const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh * 0.99) : -INFINITY;       // the fp32 screen keeps a 1 % margin
     const double thr_def = wt_thresh * (1.0 + 1e-3);              // above this a weight is stacked whatever the maximum turns out to be
-    const double lref = uniform_d(src.lnl_of_chi2(K));            // ln L at the mode: the reference of every weight
+    auto lnl_c2 = [&](double c2) { return KRT ? src.lnl_of_chi2_k(c2, 0.5 * K) : src.lnl_of_chi2(c2); };
+    auto exactw_tab = [&](double c2, const FastTabs& t, auto small) {
+        if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
+        else return hist_exactw<WP, decltype(small)::value>(c2, t);
+    };
+    const float halfk = 0.5f * (float)K;
+    const double lref = uniform_d(lnl_c2(K));                     // ln L at the mode: the reference of every weight
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t g = gw + rnd * nwaves;
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         // one candidate (exact chi2, label index, all lanes of `act`): evidence share, best chi2 on either
         // side of the mode, histogram add or ambiguous list
         auto settle = [&](int o, bool act, double c2, int tag) {
-            const double w = act ? hist_exactw<WP, !EXACT>(c2, tbx) : 0.0;
+            const double w = act ? exactw_tab(c2, tbx, std::integral_constant<bool, !EXACT>{}) : 0.0;
             hs.Sc[o] += w;
 
             const bool below = c2 <= K;
@@ -265,12 +311,15 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 // branch, follow), and the next trip's records are requested before the current ones are used
                 constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
                 static_assert((TILE / 64) % MP == 0, "groups per trip must divide the tile");
-                typename SRC::MR mn[MP];
+                constexpr bool PF = hist_prefetch<SRC, SCRB>();
+                typename SRC::MR mn[PF ? MP : 1];
                 int tagn[MP];
+                if constexpr (PF) {
 #pragma unroll
-                for (int q = 0; q < MP; ++q) {
-                    src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
-                    tagn[q] = SCRB ? 0 : tags[q * 64 + lane];
+                    for (int q = 0; q < MP; ++q) {
+                        src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
+                        tagn[q] = SCRB ? 0 : tags[q * 64 + lane];
+                    }
                 }
 #pragma unroll
                 for (int st = 0; st < TILE / 64; st += MP) {
@@ -278,10 +327,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     int ptag[MP];
 #pragma unroll
                     for (int q = 0; q < MP; ++q) {
-                        m[q] = mn[q]; ptag[q] = tagn[q];
+                        if constexpr (PF) { m[q] = mn[q]; ptag[q] = tagn[q]; }
+                        else { src.template load_model_lds<TILE>(cur, (st + q) * 64 + lane, m[q]); ptag[q] = SCRB ? 0 : tags[(st + q) * 64 + lane]; }
                         asm volatile("" : "+v"(ptag[q]));         // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
                     }
-                    if (st + MP < TILE / 64) {
+                    if (PF && st + MP < TILE / 64) {
 #pragma unroll
                         for (int q = 0; q < MP; ++q) {
                             src.template load_model_lds<TILE>(cur, (st + MP + q) * 64 + lane, mn[q]);
@@ -302,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         for (int o = 0; o < TW; ++o) {
                             // every pair in fp64; the running best (of the exact weights) bounds what can still be stacked
                             const bool valid = !TAIL || j < M;
-                            const double w = valid ? hist_exactw<WP, false>(c2[0][o], tbx) : 0.0;
+                            const double w = valid ? exactw_tab(c2[0][o], tbx, std::false_type{}) : 0.0;
                             hs.S[o] += w;
                             hs.Sc[o] = vmax_raw(hs.Sc[o], w);       // (EXACT: Sc holds the best weight seen: the bar of the ambiguous band, and ln-max at the end)
                             if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag[0] + w0], w);
@@ -330,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                 const float cf = (float)c2[q][o];
                                 const float l2 = __builtin_amdgcn_logf(cf);             // chi2 == 0: -inf; a negative screen value: nan
                                 const float df = (float)(c2[q][o] - K);                 // fp64 difference, then fp32
-                                tl[q][o] = fmaf(l2, 0.5f * WP, fmaf(df, -0.72134752f, T0));   // -inf for chi2 == 0; nan only beyond fp32's range
+                                tl[q][o] = fmaf(l2, halfk, fmaf(df, -0.72134752f, T0));   // -inf for chi2 == 0; nan only beyond fp32's range
                             }
 #pragma unroll
                         for (int q = 0; q < MP; ++q)
@@ -407,8 +457,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     lbest = (wbest_run > 0.0) ? uniform_d(lref + log_pos(wbest_run, tb)) : -INFINITY;
                 } else {
                     const double l = wave_max(hs.lo[o]), h = -wave_max(-hs.hi[o]);
-                    const double ll = (l >= 0.0) ? src.lnl_of_chi2(l) : -INFINITY;
-                    const double lh = (h < 1e299) ? src.lnl_of_chi2(h) : -INFINITY;
+                    const double ll = (l >= 0.0) ? lnl_c2(l) : -INFINITY;
+                    const double lh = (h < 1e299) ? lnl_c2(h) : -INFINITY;
                     lbest = uniform_d(fmax(ll, lh));
                 }
                 const double stot = EXACT ? wave_sum(hs.S[o]) : wave_sum(hs.Sc[o]) + wave_sum(hs.S[o] + (double)hs.s[o]);
@@ -428,9 +478,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         const int k = c0 + lane;
                         const bool in1 = k < na;
                         const Cand e1 = cb[in1 ? k : 0];
-                        const double l1 = in1 ? src.lnl_of_chi2(e1.lnl) : -INFINITY;
+                        const double l1 = in1 ? lnl_c2(e1.lnl) : -INFINITY;
                         const bool s1 = in1 && (exp_neg(l1 - le, tb) > thr);   // strict
-                        if (s1) unsafeAtomicAdd(&row[e1.j + w0], hist_exactw<WP>(e1.lnl, tb));
+                        if (s1) unsafeAtomicAdd(&row[e1.j + w0], exactw_tab(e1.lnl, tb, std::false_type{}));
                     }
                 }
                 if (lane == 0) {

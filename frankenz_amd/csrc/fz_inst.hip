@@ -89,6 +89,24 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
 #endif
+#if !FZ_EXACT_BT
+    // 9-32 bands without a masked REAL band on tame data: the one-pass histogram kernel in its mask-free form (fz_hist.h: the pad
+    // bands up to 16 / 32 are zeros, the power of chi2 follows the real band count); every other case of these band counts --
+    // masks, a prior, the KDE forms k_hist does not take -- runs the masked variants
+    if ((var == VAR_FAST || var == VAR_PAD) && !c->prior.tab) {
+        int r = 1;
+        switch (mode) {
+            case 0: { PhotSrc<FZ_BT, 0, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, 0, dim_prior);
+                      r = fz_launch_hist_only(c, ph, n, M, ko, lmap, levid, pdfs); } break;
+            case 1: { PhotSrc<FZ_BT, 1, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, 1, dim_prior);
+                      r = fz_launch_hist_only(c, ph, n, M, ko, lmap, levid, pdfs); } break;
+            case 2: { PhotSrc<FZ_BT, 2, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, 2, dim_prior);
+                      r = fz_launch_hist_only(c, ph, n, M, ko, lmap, levid, pdfs); } break;
+            default: break;
+        }
+        if (r <= 0) return r;
+    }
+#endif
     FZ_SWITCH(FZ_CALL_FUSED)
     return 0;
 }

@@ -74,6 +74,10 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     __device__ __forceinline__ double lnl_of_chi2(double chi2) const {
         return chi2_logpdf<true>(0.5 * WPOW, chi2, P::lp.lg_full, P::tb);
     }
+    // the same with the half power given at run time (band counts padded up to BT; lg_full is that of the real count)
+    __device__ __forceinline__ double lnl_of_chi2_k(double chi2, double halfk) const {
+        return chi2_logpdf<true>(halfk, chi2, P::lp.lg_full, P::tb);
+    }
     __device__ __forceinline__ double lnl(const OR& o, const typename P::MR& m, int64_t j, bool valid) const {
         double l = P::eval(o, m).lnl;             // pad lanes hold benign data; no divergent branch
         if (PRI) l += valid ? o.prow[j] : 0.0;

@@ -447,26 +447,51 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
 template <class SRC>
 int fz_launch_hist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                    double* lmap, double* levid, double* pdfs, bool exact) {
-    if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 6)) return 1;
+    // exact band counts without masks: 4-8 bands, and the wide sets (16, 32 bands) except 32 bands with per-model errors, whose
+    // object and record (192 doubles) leave the register file no room (k_fused keeps that case)
+    if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 30) || (SRC::NB > 16 && SRC::LMODE == 0)) return 1;
     else {
         if (!src.lp.dim_prior || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31)) return 1;
-        int tw = 1, nw = 16;
-        if (const char* e = getenv("FZ_HIST_CFG")) sscanf(e, "%d,%d", &tw, &nw);
         constexpr bool SB = (SRC::LMODE == 2);
         const bool scrb = SB && !getenv("FZ_HIST_NOSCRB");
-        if (exact) {
-            if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            return fz_launch_hist_g<SRC, 2, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        }
-        if constexpr (SB) {
-            if (scrb) {
-                if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                return fz_launch_hist_g<SRC, 2, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        if constexpr (SRC::NB > 8) {
+            // wide records: one object per wave, eight waves per block (up to 256 registers per lane)
+            if (getenv("FZ_HIST_WIDE") && atoi(getenv("FZ_HIST_WIDE")) == 0) return 1;
+            if (exact) return fz_launch_hist_g<SRC, 1, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            if constexpr (SB) {
+                if (scrb) return fz_launch_hist_g<SRC, 1, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             }
+            return fz_launch_hist_g<SRC, 1, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+        } else {
+            int tw = 1, nw = 16;
+            if (const char* e = getenv("FZ_HIST_CFG")) sscanf(e, "%d,%d", &tw, &nw);
+            if (exact) {
+                if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                return fz_launch_hist_g<SRC, 2, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            }
+            if constexpr (SB) {
+                if (scrb) {
+                    if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                    return fz_launch_hist_g<SRC, 2, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+                }
+            }
+            if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            return fz_launch_hist_g<SRC, 2, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         }
-        if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-        return fz_launch_hist_g<SRC, 2, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
     }
+}
+
+// k_hist or nothing (+1): the wide band sets (16 / 32 real bands, no masks), whose other kernels exist in the masked variants only
+template <class SRC>
+int fz_launch_hist_only(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap, double* levid, double* pdfs) {
+    fz::KdeView kv;
+    FZCHK(fz_kde_view(c, kv));
+    if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0)) return 1;
+    const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
+    fz_exact_now() = exact;
+    const int r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact);
+    if (r <= 0) c->last_form = exact ? "k_hist<exact>" : "k_hist<screen>";
+    return r;
 }
 
 // object-per-lane single pass (fz_ol.h); +1 = does not fit, caller takes the k_fused route

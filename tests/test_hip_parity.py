@@ -356,7 +356,10 @@ def test_wide_band_sets_unmasked(B, kw):
                                  lprob_kwargs=kw, return_gof=True, verbose=False, save_fits=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
-    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, **EVID64)      # padded band counts: the all-fp64 ln-space bodies
+    # 17-32 bands with per-model errors (no room in the register file), without the dimensionality prior, or mode C: the all-fp64
+    # ln-space bodies; with the free scale: the one-pass kernel (fp32 remainder in the evidence)
+    modeB = kw.get('free_scale') and kw.get('ignore_model_err')
+    close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9); close(le, rle, **(EVID if modeB else EVID64))
     bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
     rf = fo.bruteforce_fit(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, **kw)
     close(bf.fit_lnprob, rf['lnlike'], rtol=1e-8, atol=1e-8)
@@ -916,3 +919,35 @@ def test_uploads_are_remembered_by_content_and_in_place_edits_are_seen():
     rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od)
     close(p2, rp, rtol=1e-8, atol=1e-14); close(lm2, rlm, rtol=1e-10); close(le2, rle, **EVID)
     assert np.abs(p2 - p0).max() > 1e-3
+
+
+@pytest.mark.parametrize('B', [9, 12, 16, 20, 32])
+@pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}, {'ignore_model_err': True}])
+@pytest.mark.parametrize('err', ['const', 'varying'])
+def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err):
+    """9-32 real bands without masks (the reference's COSMOS list holds 32 filters): the one-pass histogram kernel in its mask-free
+    form on the 16- / 32-band instantiations (pad bands are zeros; the power of chi2 is that of the real band count), one object
+    per wave and eight waves per block -- against the oracle, default and all-fp64 evidence."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(900 + B)
+    M, N = 2600, 150
+    sig = rs.uniform(0.3, 2.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .5, size=(M, B))
+    Ye = np.tile(0.3 * sig, (M, 1)) if err == 'const' else 0.04 * Y
+    Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .1, N)[:, None] + sig * rs.randn(N, B)
+    Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    bf = BruteForce(Y, Ye, Ym)
+    general32 = (B > 16 and err == 'varying' and not kw)           # 17-32 bands with per-model errors: no room in the register file, masked kernels
+    for exact in (False, True):
+        lk = dict(kw, exact_evidence=True) if exact else kw
+        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=lk, return_gof=True,
+                                     verbose=False, save_fits=False)
+        form = get_engine().last_form()
+        assert form == ('k_fused' if general32 else ('k_hist<exact>' if exact else 'k_hist<screen>')), form
+        close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9)
+        close(le, rle, **(EVID64 if exact or general32 else EVID))
