@@ -374,6 +374,17 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (fl & 2) return fail(-3, "gauss_kde labels: a label's window lies wholly below the grid "
                                 "(the reference's negative-index slicing there is not reproduced)");
     c->G = G; c->label_mode = 2; c->label_M = M; c->mc_ok = false;
+    // an evenly spaced grid (every point within 1e-9 of a step of x0 + t step) lets the window adds run a two-multiplication
+    // recurrence per point (kde_scatter); anything else keeps the table exponential per point
+    c->grid_step = 0.0;
+    {
+        std::vector<double> hg((size_t)G);
+        FZCHK(copy_out(c, hg.data(), c->d_grid.p, (size_t)G * 8));
+        const double step = (hg[(size_t)G - 1] - hg[0]) / (double)(G - 1);
+        bool even = step > 0.0 && (step - step == 0.0);
+        for (int64_t t = 0; t < G && even; ++t) even = fabs(hg[(size_t)t] - (hg[0] + (double)t * step)) <= 1e-9 * step;
+        if (even) c->grid_step = step;
+    }
     return 0;
 }
 

@@ -241,6 +241,12 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             src.load_obj_lds(objs + o * OD, ob[o]);
+            if constexpr (BT > 16) {
+                // 32-band records: the object's fluxes live in SCALAR registers (they are wave-uniform; every use has room for one
+                // scalar operand), which leaves the vector file to the inverse variances and the model record
+#pragma unroll
+                for (int b = 0; b < BT; ++b) ob[o].x[b] = uniform_d(ob[o].x[b]);
+            }
             if constexpr (SCRB) {
                 Aq[o] = 0.0;
 #pragma unroll
