@@ -11,7 +11,8 @@
 // wt > wt_thresh * max(wt) (pdf.py:591) is w > wt_thresh in these units -- one ds_add_f64 into the block's histogram at
 // the entry's label index for the stacked ones.  A lane always holds the same model columns, so their label indices sit
 // in registers for the life of the block: no gathers.  Entries within 1e-9 of the threshold are decided by the
-// reference's own expression once the evidence is known (they stay in registers until then).  The next row's loads are
+// reference's own expression once the evidence is known (parked in LDS until then; a row with more of them than the block
+// parks is read once more).  The next row's loads are
 // issued before the convolution of the current one, which touches LDS and registers only (kernel taps in two registers
 // per wave, kernel masses staged in LDS), so they fly while the PDF is formed.  Everything is fp64: there is no fp32
 // remainder in the evidence and no list in HBM; traffic is the plane once and the PDFs once.
@@ -197,8 +198,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             unsafeAtomicAdd(&row[p], w * s_inv[p]);         // weight / kernel mass of the index (pdf.py:613-617)
                         } else {                                             // (rare) parked until the evidence is known
                             const int k = atomicAdd(&s_amb[0], 1);
-                            if (k < CAPA) { s_ambl[k] = lv; s_ambp[k] = p; }
-                            else if (w > wt_thresh) { unsafeAtomicAdd(&row[p], w * s_inv[p]); unsafeAtomicAdd(&s_red[3 * NW], w); }   // (beyond CAPA ties: the rule in these units)
+                            if (k < CAPA) { s_ambl[k] = lv; s_ambp[k] = p; }   // (more than CAPA of them: the row is read again below)
                         }
                     }
                 }
@@ -221,13 +221,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (ok) {
                 const double le = mx + log_by_exp(S, s_exp);
                 const double thr = wt_thresh * exp_neg(mx - le, tb);        // wt_thresh * max(wt)
-                for (int k = tid; k < min(namb, CAPA); k += NT) {
-                    const double lv = s_ambl[k];
-                    const int p = s_ambp[k];
-                    if (exp_neg(lv - le, tb) > thr) {                       // strict
-                        const double w = exp_nonpos_tab(lv - mx, s_exp);
-                        unsafeAtomicAdd(&row[p], w * s_inv[p]);
-                        unsafeAtomicAdd(&s_red[3 * NW], w);
+                if (namb <= CAPA) {
+                    for (int k = tid; k < namb; k += NT) {
+                        const double lv = s_ambl[k];
+                        const int p = s_ambp[k];
+                        if (exp_neg(lv - le, tb) > thr) {                   // strict
+                            const double w = exp_nonpos_tab(lv - mx, s_exp);
+                            unsafeAtomicAdd(&row[p], w * s_inv[p]);
+                            unsafeAtomicAdd(&s_red[3 * NW], w);
+                        }
+                    }
+                } else {
+                    // more ties than the block parks (a degenerate row): its entries are read once more and the band decided in place
+                    const double* r = plane + i * ld;
+                    for (int k = tid; k < M / 2; k += NT) {
+                        const int pt = s_tag[k];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const double lv = r[2 * k + q];
+                            const double w = exp_nonpos_tab(lv - mx, s_exp);
+                            if (w >= thr_lo && !(w > thr_hi) && exp_neg(lv - le, tb) > thr) {
+                                const int p = q ? (pt >> 16) : (pt & 0xffff);
+                                unsafeAtomicAdd(&row[p], w * s_inv[p]);
+                                unsafeAtomicAdd(&s_red[3 * NW], w);
+                            }
+                        }
                     }
                 }
             }

@@ -198,9 +198,20 @@ class NearestNeighbors():
         Ndata = len(data)
         self.NDATA = Ndata
         self._alloc_fits(Ndata)
-        scratch = HostObjects(np.array(data, dtype=float), np.array(data_err, dtype=float), np.array(data_mask, dtype=float))
-        self._run(eng, scratch, q, 0, Ndata, like_opts(None), None, False, True)     # neighbours; the default fits are overwritten below
+        # neighbours only: the K searches on the GPU (in chunks), pandas.unique's first-appearance order on the host (knn.py:834-840);
+        # no default likelihood is run for rows the callable fills anyway
         W = self.K * self.k
+        idx = np.empty((Ndata, W), dtype=np.int64)
+        for lo in range(0, Ndata, 1 << 16):
+            hi = min(lo + (1 << 16), Ndata)
+            eng.knn_query(q[lo:hi], self.k, self.dbound, idx[lo:hi], n=hi - lo, lp_norm=self.lp_norm)
+        if Ndata and (idx.min() < 0 or idx.max() >= self.NMODEL):
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (self.NMODEL, self.NMODEL))   # KDTree's "missing" index (knn.py:847)
+        for i in range(Ndata):
+            _, first = np.unique(idx[i], return_index=True)
+            nb = idx[i][np.sort(first)]
+            self.Nneighbors[i] = len(nb)
+            self.neighbors[i, :len(nb)] = nb
         inf = np.inf
         self.fit_lnprior[:] = -inf; self.fit_lnlike[:] = -inf; self.fit_lnprob[:] = -inf
         self.fit_Ndim[:] = 0; self.fit_chi2[:] = inf; self.fit_scale[:] = 1.; self.fit_scale_err[:] = 0.

@@ -951,3 +951,41 @@ def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err):
         assert form == ('k_fused' if general32 else ('k_hist<exact>' if exact else 'k_hist<screen>')), form
         close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9)
         close(le, rle, **(EVID64 if exact or general32 else EVID))
+
+
+@pytest.mark.parametrize('M', [10000, 10240, 10242, 20480])
+def test_predict_rows_in_registers_with_ties_at_the_threshold(M, monkeypatch):
+    """predict() from a stored plane whose rows fit one block's registers (k_plane_rows: exact maximum first, then fp64 weights
+    straight into the LDS histogram; 10 240 entries at 8 waves, 20 480 at 16).  Entries at ln(wt_thresh) below the best -- the
+    threshold to within rounding, by the hundred and by the thousand -- are decided by the reference's own expression
+    (pdf.py:591: wt > wt_thresh * max(wt), strict); same answers as k_plane_fused and the oracle; every output fp64."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(77 + M)
+    N, B = 90, 5
+    Y = rs.lognormal(1., 1., size=(M, B)); Ye = 0.05 * Y; Ym = np.ones((M, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    lw = -0.5 * rs.chisquare(3, size=(N, M)) * rs.choice([1.0, 30.0, 3000.0], size=(N, 1))
+    lt = np.log(1e-3)
+    for i, n_tie in ((3, 1), (4, 300), (5, 3000)):                  # ties: a few, hundreds, more than the block parks
+        best = lw[i].max()
+        where = rs.choice(M, n_tie, replace=False)
+        where = where[lw[i, where] < best]
+        # within 1e-12 of the threshold: far inside the kernel's 1e-9 band (so the parked path decides them), far enough outside
+        # the rounding of any exp for the reference's expression to decide them the same way on every implementation
+        lw[i, where] = best + lt + rs.choice([1e-13, -1e-13, 1e-12, -1e-12, 3e-11, -3e-11], len(where)) * max(1.0, abs(best))
+    lw[6, 0] = np.nan; lw[7, 99] = np.nan; lw[8, 5] = np.inf; lw[9, :] = -np.inf; lw[10, :] = -3.25
+    bf = BruteForce(Y, Ye, Ym)
+    with np.errstate(all='ignore'):
+        p1, (lm1, le1) = bf.predict(z, ze, label_dict=d, logwt=lw.copy(), return_gof=True, verbose=False)
+        assert get_engine().last_form() == 'k_plane_rows'
+        monkeypatch.setenv('FZ_PLANE_ROWS', '0')
+        p2, (lm2, le2) = bf.predict(z, ze, label_dict=d, logwt=lw.copy(), return_gof=True, verbose=False,
+                                    kde_kwargs={'exact_evidence': True})
+        assert get_engine().last_form() == 'k_plane_fused'
+        monkeypatch.delenv('FZ_PLANE_ROWS')
+        rp, rlm, rle = fo.bruteforce_predict(lw, z, ze, label_dict=od)
+    close(lm1, rlm, rtol=0, atol=0); close(le1, rle, rtol=1e-13, atol=1e-12)
+    close(p1, rp, rtol=1e-9, atol=1e-15); close(p1, p2, rtol=1e-9, atol=1e-15)
+    close(lm1, lm2, rtol=0, atol=0); close(le1, le2, rtol=1e-13, atol=1e-12)

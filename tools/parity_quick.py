@@ -18,13 +18,21 @@ pd, od = PDFDict(grid, sgrid), fo.KernelDict(grid, sgrid)
 worst = 0
 for name, Ye, kw in (("A const", np.tile(sig, (M, 1)), {}), ("A varying", np.tile(sig, (M, 1)) * rs.uniform(.5, 1.5, (M, B)), {}),
                      ("Ai", np.tile(sig, (M, 1)), {'ignore_model_err': True}), ("B", np.tile(sig, (M, 1)), {'free_scale': True, 'ignore_model_err': True})):
-    p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=pd, lprob_kwargs=kw,
-                                                    return_gof=True, save_fits=False, verbose=False)
-    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    if os.environ.get("PQ_KDE") == "grid":               # the direct gauss_kde (no dictionary), a few wide kernels among the labels
+        zz = ze.copy(); zz[::97] = 0.4
+        p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, zz, label_grid=grid, lprob_kwargs=kw,
+                                                        return_gof=True, save_fits=False, verbose=False)
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, zz, label_grid=grid, **kw)
+    else:
+        p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=pd, lprob_kwargs=kw,
+                                                        return_gof=True, save_fits=False, verbose=False)
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     dl, de = np.nanmax(np.abs(lm - rlm) / np.maximum(1, np.abs(rlm))), np.nanmax(np.abs(le - rle) / np.maximum(1, np.abs(rle)))
     dp = np.nanmax(np.abs(p - rp))
+    from frankenz_amd.engine import get_engine
+    name = name + ' [' + get_engine().last_form() + ']'
     nanmis = int((np.isnan(p) != np.isnan(rp)).sum())
-    print("%-10s lmap %.2e  levid %.2e  pdf abs %.2e  nan-mismatch %d" % (name, dl, de, dp, nanmis), flush=True)
+    print("%-28s lmap %.2e  levid %.2e  pdf abs %.2e  nan-mismatch %d" % (name, dl, de, dp, nanmis), flush=True)
     worst = max(worst, dl, dp * 1e3, nanmis)
     if not (dl < 1e-11 and de < 1e-7 and dp < 1e-11 and nanmis == 0):
         bad = np.argsort(-np.nanmax(np.abs(p - rp), axis=1))[:5]
