@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_planes(PH ph_, int64_t N, int64_t M, do
 }
 
 // ---- KDE tables ------------------------------------------------------------------
+typedef double fz_d2l __attribute__((ext_vector_type(2)));
 struct KdeView {
     int64_t G;
     int kmode;             // KDE_HIST / KDE_DICT / KDE_GRID
@@ -234,6 +235,7 @@ struct KdeView {
     const double* ly; const double* lstd; const int32_t* lo; const int32_t* hi;
     const double* grid;
     double gstep;                         // direct path: the grid's spacing when it is evenly spaced (to 1e-9 of a step), else 0
+    const double* lrec;                   // direct path, even grid: 48-byte record per model (k_prep_grid_labels)
     int acc_stride;                       // doubles of LDS per object
     int lane_window;                      // DICT / GRID: windows up to this many grid points are added by their own lane
     // class-sorted dictionary stack (k_fused<..., MC>): the kernel's model records are ordered by
@@ -271,6 +273,29 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
                 for (int t = lo; t < hi; ++t) unsafeAtomicAdd(&row[t], wn * kr[t]);
             }
         }
+    } else if (kv.gstep > 0.0) {
+        // evenly spaced grid: with z_t = (x_t - mu) / sd and h = step / sd the Gaussian obeys G_{t+1} = G_t R_t, R_{t+1} = R_t e^{-h^2},
+        // R_t = exp(-z_t h - h^2 / 2): two exponentials per window and two multiplications per point instead of a table exponential
+        // (and a grid load) per point; the products are re-seeded every 64 points, so the accumulated rounding stays below ~3e-13
+        // relative.  What the window needs comes from the model's 48-byte record.
+        if (sel) {
+            const fz_d2l* rec = reinterpret_cast<const fz_d2l*>(kv.lrec + 6 * jm);
+            const fz_d2l ra = rec[0], rb = rec[1], rc = rec[2];
+            const int lo = __double2loint(rc.x), hi = __double2hiint(rc.x);
+            wide = hi - lo > kv.lane_window;
+            if (!wide && rb.x != 0.0) {                          // pdf.py:523: kernels with zero sum are skipped
+                const double mu = ra.x, isd = ra.y, q = rb.y;
+                const double wg = w * rb.x, h = kv.gstep * isd;
+                const FastTabs tb = global_tabs();
+                for (int t0 = lo; t0 < hi; t0 += 64) {
+                    const double z = (kv.grid[t0] - mu) * isd;
+                    double g = wg * exp_neg(-0.5 * (z * z), tb);
+                    double r = exp_clamped(-fma(z, h, 0.5 * (h * h)), tb);
+                    const int t1 = min(t0 + 64, hi);
+                    for (int t = t0; t < t1; ++t) { unsafeAtomicAdd(&row[t], g); g *= r; r *= q; }
+                }
+            }
+        }
     } else {
         if (sel) {
             const int lo = kv.lo[jm], hi = kv.hi[jm];
@@ -280,26 +305,9 @@ __device__ __forceinline__ void kde_scatter(const KdeView& kv, double* row, bool
                 const double mu = kv.ly[jm], sd = kv.lstd[jm];
                 const double isd = 1.0 / sd;
                 const double wg = (w / nrm) / (2.5066282746310002 * sd);      // weight / (sqrt(2 pi) * std)
-                if (kv.gstep > 0.0) {
-                    // evenly spaced grid: with z_t = (x_t - mu) / sd and h = step / sd the Gaussian obeys
-                    // G_{t+1} = G_t R_t, R_{t+1} = R_t e^{-h^2}, R_t = exp(-z_t h - h^2 / 2): three exponentials per window and two
-                    // multiplications per point instead of a table exponential (and a grid load) per point; the products are
-                    // re-seeded every 64 points, so the accumulated rounding stays below ~3e-13 relative
-                    const double h = kv.gstep * isd;
-                    const FastTabs tb = global_tabs();
-                    const double q = exp_neg(-(h * h), tb);
-                    for (int t0 = lo; t0 < hi; t0 += 64) {
-                        const double z = (kv.grid[t0] - mu) * isd;
-                        double g = wg * exp_neg(-0.5 * (z * z), tb);
-                        double r = exp_clamped(-fma(z, h, 0.5 * (h * h)), tb);
-                        const int t1 = min(t0 + 64, hi);
-                        for (int t = t0; t < t1; ++t) { unsafeAtomicAdd(&row[t], g); g *= r; r *= q; }
-                    }
-                } else {
-                    for (int t = lo; t < hi; ++t) {
-                        const double z = (kv.grid[t] - mu) * isd;
-                        unsafeAtomicAdd(&row[t], wg * exp_neg(-0.5 * (z * z)));
-                    }
+                for (int t = lo; t < hi; ++t) {
+                    const double z = (kv.grid[t] - mu) * isd;
+                    unsafeAtomicAdd(&row[t], wg * exp_neg(-0.5 * (z * z)));
                 }
             }
         }

@@ -26,6 +26,7 @@ inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
         kv.ly = c->d_ly.as<double>(); kv.lstd = c->d_lstd.as<double>(); kv.lo = c->d_lo.as<int32_t>(); kv.hi = c->d_hi.as<int32_t>();
         kv.grid = c->d_grid.as<double>();
         kv.gstep = getenv("FZ_GRID_RECUR") && atoi(getenv("FZ_GRID_RECUR")) == 0 ? 0.0 : c->grid_step;
+        kv.lrec = c->d_lrec.as<double>();
         kv.kmode = KDE_GRID; kv.acc_stride = (int)c->G;
     }
     kv.lane_window = getenv("FZ_LANE_WINDOW") ? atoi(getenv("FZ_LANE_WINDOW")) : FZ_LANE_WINDOW;
