@@ -428,7 +428,7 @@ def main():
             try:
                 for ent in json.load(open(prof)).get("entries", []):
                     if ent.get("form") == form and ent.get("mode") == args.mode and ent.get("model_err") == args.model_err \
-                            and abs(ent.get("evals_per_launch", 0) - evals_per_launch) <= 0.01 * evals_per_launch:
+                            and ent.get("n_band", 5) == args.nband and abs(ent.get("evals_per_launch", 0) - evals_per_launch) <= 0.01 * evals_per_launch:
                         traffic = ent["hbm_bytes_per_launch"]; traffic_src = ent.get("source")
             except Exception:
                 traffic = None
