@@ -117,11 +117,19 @@ __device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTa
 
 // models per LDS tile by record width: two tiles, the histograms and the candidate buffers share 160 KB
 template <class SRC>
-constexpr int hist_tile() { return SRC::RW <= 18 ? 256 : (SRC::RW <= 34 ? 128 : 64); }
+constexpr int hist_tile() {
+    // 16 waves per block (up to 8 bands): 256-model tiles up to 10 doubles per record, 128 beyond (6-8 bands with per-model errors:
+    // 14-18 doubles); 8 waves per block (the wide instantiations): 256 up to 18 doubles, 128 up to 34, 64 beyond
+    if (SRC::NB <= 8) return SRC::RW <= 10 ? 256 : 128;
+    return SRC::RW <= 18 ? 256 : (SRC::RW <= 34 ? 128 : 64);
+}
 // wide records: the next step's model record is NOT requested ahead where a second copy of the record does not fit the
 // register file beside the object (16 bands with per-model errors or the closed-form screen, 32 bands)
 template <class SRC, bool SCRB>
-constexpr bool hist_prefetch() { return 2 * SRC::NB + 2 * SRC::RW + (SCRB ? 2 * SRC::NB : 0) <= 96; }
+constexpr bool hist_prefetch() {
+    if (SRC::NB <= 8) return SRC::NB + SRC::NVAL <= 18;              // 16 waves per block, 128 registers: all but 7 / 8 bands with per-model errors
+    return 2 * SRC::NB + 2 * SRC::RW + (SCRB ? 2 * SRC::NB : 0) <= 96;
+}
 
 // wave-wide maximum of a float without the LDS pipe: DPP within rows of 16 lanes, then the four row results through scalar
 // registers; the result is wave-uniform (lanes hold the same SGPR-fed value)
