@@ -989,3 +989,39 @@ def test_predict_rows_in_registers_with_ties_at_the_threshold(M, monkeypatch):
     close(lm1, rlm, rtol=0, atol=0); close(le1, rle, rtol=1e-13, atol=1e-12)
     close(p1, rp, rtol=1e-9, atol=1e-15); close(p1, p2, rtol=1e-9, atol=1e-15)
     close(lm1, lm2, rtol=0, atol=0); close(le1, le2, rtol=1e-13, atol=1e-12)
+
+
+def test_wide_and_grid_switches_do_not_change_results(monkeypatch):
+    """FZ_HIST_WIDE=0 (12 bands back on the masked kernels) and FZ_GRID_RECUR=0 (a table exponential per window point of the
+    direct gauss_kde instead of the recurrence on the evenly spaced grid): same PDFs; an uneven grid keeps the per-point form."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(321)
+    M, N, B = 1500, 300, 12
+    sig = rs.uniform(0.3, 2.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .5, size=(M, B)); Ye = np.tile(0.3 * sig, (M, 1)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .1, N)[:, None] + sig * rs.randn(N, B); Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = rs.uniform(0.02, 0.3, M)
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda **kw: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, np.full(M, 0.05), return_gof=True, save_fits=False, verbose=False, **kw)
+    p0, (lm0, le0) = run(label_dict=d)
+    assert get_engine().last_form() == 'k_hist<screen>'
+    monkeypatch.setenv('FZ_HIST_WIDE', '0')
+    p1, (lm1, le1) = run(label_dict=d)
+    assert get_engine().last_form() == 'k_fused'
+    monkeypatch.delenv('FZ_HIST_WIDE')
+    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
+    grid = np.arange(0., 7. + 1e-5, 0.01)
+    rung = lambda g: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_grid=g, return_gof=True, save_fits=False, verbose=False)
+    q0, (qm0, qe0) = rung(grid)
+    monkeypatch.setenv('FZ_GRID_RECUR', '0')
+    q1, (qm1, qe1) = rung(grid)
+    monkeypatch.delenv('FZ_GRID_RECUR')
+    close(q1, q0, rtol=1e-10, atol=1e-15); close(qm1, qm0, rtol=1e-13); close(qe1, qe0, rtol=1e-13, atol=1e-12)
+    rq, rqm, rqe = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_grid=grid)
+    close(q0[:40], rq, rtol=1e-8, atol=1e-14)
+    bent = grid.copy(); bent[300:] += 3e-4                             # not evenly spaced (3 % of a step): the recurrence is not used
+    u0, _ = rung(bent)
+    ru, _, _ = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_grid=bent)
+    close(u0[:40], ru, rtol=1e-8, atol=1e-14)
