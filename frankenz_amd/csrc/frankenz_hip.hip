@@ -127,7 +127,7 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
     if (fl) atomicOr(flags, fl);
 }
 
-static int pick_bt(int B) { return (B >= 4 && B <= 8) ? B : (B < 4 ? 4 : (B <= 16 ? 16 : (B <= 32 ? 32 : 0))); }
+static int pick_bt(int B) { return (B >= 4 && B <= 8) ? B : (B < 4 ? 4 : (B <= 12 ? 12 : (B <= 16 ? 16 : (B <= 24 ? 24 : (B <= 32 ? 32 : 0))))); }
 
 extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, const double* ym, int64_t M, int32_t B) {
     if (!c || !y || !ye || !ym) return fail(-1, "fz_models_upload: NULL argument");
@@ -503,7 +503,9 @@ static int run_planes(fz_ctx* c, int mode, int var, int dp, int64_t n, double* l
         case 6: return fz_planes_bt6(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
         case 7: return fz_planes_bt7(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
         case 8: return fz_planes_bt8(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        case 12: return fz_planes_bt12(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
         case 16: return fz_planes_bt16(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
+        case 24: return fz_planes_bt24(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
         default: return fz_planes_bt32(c, mode, var, dp, n, lnl, chi2, ndim, scale, serr);
     }
 }
@@ -515,7 +517,9 @@ static int run_fitpredict(fz_ctx* c, int mode, int var, int dp, int64_t n, const
         case 6: return fz_fitpredict_bt6(c, mode, var, dp, n, ko, lmap, levid, pdfs);
         case 7: return fz_fitpredict_bt7(c, mode, var, dp, n, ko, lmap, levid, pdfs);
         case 8: return fz_fitpredict_bt8(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        case 12: return fz_fitpredict_bt12(c, mode, var, dp, n, ko, lmap, levid, pdfs);
         case 16: return fz_fitpredict_bt16(c, mode, var, dp, n, ko, lmap, levid, pdfs);
+        case 24: return fz_fitpredict_bt24(c, mode, var, dp, n, ko, lmap, levid, pdfs);
         default: return fz_fitpredict_bt32(c, mode, var, dp, n, ko, lmap, levid, pdfs);
     }
 }
@@ -527,7 +531,9 @@ static int run_modec(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, const
         case 6: return fz_modec_bt6(c, var, n, o, nbr, nnb, W);
         case 7: return fz_modec_bt7(c, var, n, o, nbr, nnb, W);
         case 8: return fz_modec_bt8(c, var, n, o, nbr, nnb, W);
+        case 12: return fz_modec_bt12(c, var, n, o, nbr, nnb, W);
         case 16: return fz_modec_bt16(c, var, n, o, nbr, nnb, W);
+        case 24: return fz_modec_bt24(c, var, n, o, nbr, nnb, W);
         default: return fz_modec_bt32(c, var, n, o, nbr, nnb, W);
     }
 }

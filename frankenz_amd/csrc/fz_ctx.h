@@ -225,6 +225,8 @@ FZ_DECL_BT(5)
 FZ_DECL_BT(6)
 FZ_DECL_BT(7)
 FZ_DECL_BT(8)
+FZ_DECL_BT(12)
 FZ_DECL_BT(16)
+FZ_DECL_BT(24)
 FZ_DECL_BT(32)
 #undef FZ_DECL_BT

@@ -1,7 +1,7 @@
 // Per-band-count instantiations of the photometric kernels.  Compiled once per
-// FZ_BT in {4, 5, 6, 7, 8, 16, 32} (separate translation units so they build in parallel).
+// FZ_BT in {4, 5, 6, 7, 8, 12, 16, 24, 32} (separate translation units so they build in parallel).
 #ifndef FZ_BT
-#error "compile with -DFZ_BT=4|5|6|7|8|16|32"
+#error "compile with -DFZ_BT=4|5|6|7|8|12|16|24|32"
 #endif
 #include "fz_ctx.h"
 #include "fz_kernels.h"

@@ -11,5 +11,7 @@ FZ_STUB_BT(4)
 FZ_STUB_BT(6)
 FZ_STUB_BT(7)
 FZ_STUB_BT(8)
+FZ_STUB_BT(12)
 FZ_STUB_BT(16)
+FZ_STUB_BT(24)
 FZ_STUB_BT(32)
