@@ -101,12 +101,17 @@ inline int fz_launch_plane_rows(fz_ctx* c, const double* plane, const fz::KdeVie
                                 double* lmap, double* levid, double* pdfs) {
     const int64_t G = kv.G, w2 = 2 * (int64_t)kv.w0;
     if (w2 >= 128 || G + w2 > 65535 || G + w2 > kv.acc_stride || G > 8 * 128) return 1;
-    int nw = 8, e2 = 10;
+    // shapes: 5 120 entries (8 waves x 5 register pairs), 10 240 (8 x 10), 20 480 (16 x 10); a row must fill 80 % of its shape
+    // (a 15 000-entry row on the 20 480 shape is slower than k_plane_fused: 2.56 vs 2.40 ms per 66 000 rows)
+    int nw = 0, e2 = 0;
     if (const char* e = getenv("FZ_PLANE_ROWS_CFG")) sscanf(e, "%d,%d", &nw, &e2);
-    else if (M > 8 * 64 * 2 * 10) { nw = 16; e2 = 10; }
-    if (M > (int64_t)nw * 64 * 2 * e2) return 1;
+    else if (M <= 5120) { nw = 8; e2 = 5; }
+    else if (M <= 10240) { nw = 8; e2 = 10; }
+    else { nw = 16; e2 = 10; }
+    const int64_t capn = (int64_t)nw * 64 * 2 * e2;
+    if (M > capn || (!getenv("FZ_PLANE_ROWS_CFG") && M * 5 < capn * 4)) return 1;
+    if (nw == 8 && e2 == 5) return fz_launch_plane_rows_g<8, 5>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
     if (nw == 8 && e2 == 10) return fz_launch_plane_rows_g<8, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
-    if (nw == 16 && e2 == 5) return fz_launch_plane_rows_g<16, 5>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
     if (nw == 16 && e2 == 10) return fz_launch_plane_rows_g<16, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
     return 1;
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
 }
 
 template <int NW, int E2>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plane_rows(const double* __restrict__ plane, int64_t ld, const KdeView* __restrict__ kvp,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_plane_rows(const double* __restrict__ plane, int64_t ld, const KdeView* __restrict__ kvp,
                                                          int acc_stride, int64_t N, int M, double wt_thresh, int normalize,
                                                          double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs) {
     constexpr int NT = NW * 64, CAPA = NT;

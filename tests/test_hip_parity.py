@@ -953,10 +953,10 @@ def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err):
         close(le, rle, **(EVID64 if exact or general32 else EVID))
 
 
-@pytest.mark.parametrize('M', [10000, 10240, 10242, 20480])
+@pytest.mark.parametrize('M', [4100, 5120, 10000, 10240, 17000, 20480])
 def test_predict_rows_in_registers_with_ties_at_the_threshold(M, monkeypatch):
     """predict() from a stored plane whose rows fit one block's registers (k_plane_rows: exact maximum first, then fp64 weights
-    straight into the LDS histogram; 10 240 entries at 8 waves, 20 480 at 16).  Entries at ln(wt_thresh) below the best -- the
+    straight into the LDS histogram; shapes of 5 120, 10 240 and 20 480 entries, used when a row fills 80 % of one).  Entries at ln(wt_thresh) below the best -- the
     threshold to within rounding, by the hundred and by the thousand -- are decided by the reference's own expression
     (pdf.py:591: wt > wt_thresh * max(wt), strict); same answers as k_plane_fused and the oracle; every output fp64."""
     from frankenz_amd import BruteForce
