@@ -166,7 +166,10 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
         for buf in (pdfs, lm, le):
             out_v, in_v = buf[base:base + world * cs], buf[lo:lo + cs]
             if nccl:
-                works.append(dist.all_gather_into_tensor(out_v, in_v, group=group, async_op=True))
+                try:                                             # in place: rank r's rows already sit at offset r cs of the slab
+                    works.append(dist.all_gather_into_tensor(out_v, in_v, group=group, async_op=True))
+                except (RuntimeError, ValueError):               # a build that refuses overlapping views: one copy of the rank's rows
+                    works.append(dist.all_gather_into_tensor(out_v, in_v.clone(), group=group, async_op=True))
             else:                                                # gloo (tests, several ranks on one GPU): through host memory
                 tmp = torch.empty(out_v.shape, dtype=out_v.dtype)
                 dist.all_gather_into_tensor(tmp, in_v.cpu(), group=group)

@@ -79,3 +79,31 @@ def test_configs4_substitute_catalogue_to_stacked_nz(tag, world, tmp_path):
         ll, ov = samplers.loglike_nz(nzv, p, return_overlap=True)
         np.testing.assert_allclose(ov, g['%s_overlap_%s' % (tag, nm)], rtol=1e-8, atol=1e-300)
         np.testing.assert_allclose(ll, float(g['%s_llnz_%s' % (tag, nm)]), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_rccl_accepts_the_in_place_gather_of_the_overlapped_path():
+    """The overlapped sharded call hands RCCL a slab of the result and, as input, the rank's own rows INSIDE that slab
+    (`all_gather_into_tensor` in place, async).  A one-rank `nccl` group on the box's GPU runs that exact call form through
+    RCCL (a fresh process: the suite's own process holds no process group); more ranks need more GPUs (bench.py --gpus N)."""
+    import subprocess, sys, os
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+buf = torch.arange(12 * 7, dtype=torch.float64, device="cuda").reshape(12, 7).clone()
+ref = buf.clone()
+works = []
+for base in (0, 4, 8):
+    out_v, in_v = buf[base:base + 4], buf[base:base + 4]
+    works.append(dist.all_gather_into_tensor(out_v, in_v, async_op=True))
+for w in works: w.wait()
+torch.cuda.synchronize()
+assert torch.equal(buf, ref)
+dist.destroy_process_group()
+print("RCCL_IN_PLACE_OK")
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "RCCL_IN_PLACE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,2 +1,2 @@
 #!/bin/bash
-python3 -m pytest tests -m gpu -x -q -k "predict or plane or modec or rows" --tb=short 2>&1 | tail -4
+python3 -m pytest tests/test_hip_sharded.py -m gpu -x -q --tb=short 2>&1 | tail -6
