@@ -423,7 +423,9 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
             if (!(e2 > 1e-30 && e2 < 1e30) || !(fabs(f) < 1e30)) fl |= 4;
             sl += log(e2);
             fx = f;
-            v = (vmode == 0) ? e2 : 1.0 / e2;
+            // modes Ai / B: an unobserved band carries inverse variance 0 -- it then adds exactly nothing to chi2, inter and shape in the
+            // mask-free arithmetic as well (the masked kernels multiply the term by the mask anyway)
+            v = (vmode == 0) ? e2 : (mk != 0.0 ? 1.0 / e2 : 0.0);
         }
         if (derive) { ox[i * BT + b] = fx; ov[i * BT + b] = v; }
     }
@@ -841,7 +843,14 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
             // When the models themselves are unmasked, the (usually large) share of objects with
             // every band observed keeps the mask-free kernels: the chunk is split in two launches.
             bool done = false;
-            if (var == VAR_MASKED && !c->models_real_masked && (c->BT == c->B || c->BT > 8) && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
+            // objects with unobserved bands, unmasked models, modes Ai / B: the one-pass kernel with per-object band counts takes the whole
+            // chunk (masked and fully observed objects alike); where it does not apply (+1) the chunk is split as before
+            if (var == VAR_MASKED && !c->models_real_masked && mode != 0 && !c->prior.tab) {
+                const int r0 = run_fitpredict(c, mode, VAR_OBJMASK, o->dim_prior, n, ko, d_lm, d_le, d_pdf);
+                if (r0 < 0) return r0;
+                done = (r0 == 0);
+            }
+            if (!done && var == VAR_MASKED && !c->models_real_masked && (c->BT == c->B || c->BT > 8) && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
                 FZCHK(c->d_omap.ensure((size_t)n * 8 + 64));
                 int* fast = c->d_omap.as<int>(); int* slow = fast + n; int* counts = slow + n;
                 HIPCHK(hipMemsetAsync(counts, 0, 8, c->stream));

@@ -78,8 +78,10 @@ __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg
 //      with Newton-refined reciprocals
 //   2  anything else (zero/huge/non-finite variances): IEEE division throughout
 enum { VAR_FAST = 0, VAR_MASKED = 1, VAR_SAFE = 2,
-       VAR_PAD = 3 };    // host-side only: tame, no REAL band masked, but the band count is padded up to 16 / 32 -- the one-pass kernel runs its
-                         // mask-free form (pad bands are zeros and add nothing), every other kernel its masked variant
+       VAR_PAD = 3,      // host-side only: tame, no REAL band masked, but the band count is padded up to 12 / 16 / 24 / 32 -- the one-pass kernel
+                         // runs its mask-free form (pad bands are zeros and add nothing), every other kernel its masked variant
+       VAR_OBJMASK = 4 };// host-side only, a REQUEST: objects with unobserved bands against unmasked models in modes Ai / B -- try the one-pass
+                         // kernel with per-object band counts (masked bands carry inverse variance 0); +1 = not applicable, nothing was launched
 
 template <int BT, int MODE, int VAR>
 struct Phot {

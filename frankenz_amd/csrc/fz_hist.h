@@ -102,6 +102,7 @@ __device__ __forceinline__ double hist_exactw(double c2, const FastTabs& tb) {
 template <bool SMALL = false>
 __device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTabs& tb) {
     const double K = (double)wp;
+    if (wp == 0) return SMALL ? exp_small_tab(-0.5 * c2, tb.expt) : exp_clamped(-0.5 * c2, tb);      // wave-uniform branch
     const double r = c2 * rcp_nr<2>(K);
     double pw = 1.0, base = r;
     for (int e = wp >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }     // scalar loop
@@ -170,17 +171,22 @@ __device__ __forceinline__ double hist_screen_b(const typename SRC::OR& o, const
     return fma(-inter * rc, inter, A);
 }
 
-template <class SRC, int TW, int NW, bool EXACT, bool SCRB>
+// OBJK: the band count behind the power of chi2 is the OBJECT's (its observed bands; one object per wave, so it is wave-uniform):
+// band sets padded up to 12 / 16 / 24 / 32 bands, and objects with unobserved bands against unmasked models in modes Ai / B, where a
+// masked band carries inverse variance 0 (k_prep_objects) and adds exactly nothing to chi2 in the mask-free arithmetic.
+template <class SRC, int TW, int NW, bool EXACT, bool SCRB, bool OBJK = (SRC::NB > 8)>
 __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
                                                    double wt_thresh, int normalize, Cand* __restrict__ amb, int64_t cap,
                                                    double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs,
                                                    const int* __restrict__ omap, int* __restrict__ redo) {
     constexpr int TILE = hist_tile<SRC>(), RW = SRC::RW, TDR = RW * TILE, TD = TDR + TILE / 2, NT = NW * 64, OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW, BT = SRC::NB;
-    // wide instantiations (16 / 32 bands) also serve the band counts padded up to them: the power of chi2 follows the REAL count
-    constexpr bool KRT = (BT > 8);
-    const int wpr = __builtin_amdgcn_readfirstlane(KRT ? src_.lp.nband - (SRC::LMODE == 2 ? 3 : 2) : WP);
-    const double K = KRT ? (double)wpr : (double)WP;
+    static_assert(!OBJK || TW == 1, "per-object band counts: one object per wave");
+    constexpr bool KRT = OBJK;                                          // run-time power (set per object below)
+    int wpr = WP;
+    double K = (double)WP;
+    bool kok = true;                                                    // OBJK: the object's power is >= 1 (else: the exact sweep)
+    double lgq = src_.lp.lg_full;
     constexpr int NOBJ = NW * TW;
     constexpr int CAP = 128, DTHR = CAP - 64;                             // ring entries per object; drain from DTHR pending entries on
     using tag_t = typename std::conditional<SCRB, int32_t, uint16_t>::type;   // label index (< 65536, checked by the launcher) or model number
@@ -219,16 +225,19 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     tag_t* rtag = s_tag + (EXACT ? 0 : wave * (TW * CAP));
     Cand* ambw = amb + (size_t)gw * TW * cap;
     // log2 of the screening weight: t = (K/2) log2(chi2) - (chi2 - K) log2(e) / 2 - (K/2) log2(K)
-    const float T0 = (float)(-0.5 * K * log2(K));
+    float T0 = (float)(-0.5 * K * log2(K));
     const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh * 0.99) : -INFINITY;       // the fp32 screen keeps a 1 % margin
     const double thr_def = wt_thresh * (1.0 + 1e-3);              // above this a weight is stacked whatever the maximum turns out to be
-    auto lnl_c2 = [&](double c2) { return KRT ? src.lnl_of_chi2_k(c2, 0.5 * K) : src.lnl_of_chi2(c2); };
+    auto lnl_c2 = [&](double c2) {
+        if constexpr (KRT) return (wpr == 0) ? fma(-0.5, c2, -lgq) : chi2_logpdf<true>(0.5 * K, c2, lgq, tb);      // (power 0: no x log x term)
+        else return src.lnl_of_chi2(c2);
+    };
     auto exactw_tab = [&](double c2, const FastTabs& t, auto small) {
         if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
         else return hist_exactw<WP, decltype(small)::value>(c2, t);
     };
-    const float halfk = 0.5f * (float)K;
-    const double lref = uniform_d(lnl_c2(K));                     // ln L at the mode: the reference of every weight
+    float halfk = 0.5f * (float)K;
+    double lref = uniform_d(lnl_c2(K));                           // ln L at the mode: the reference of every weight
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
         const int64_t g = gw + rnd * nwaves;
@@ -240,6 +249,20 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             src.park_obj(omap ? (int64_t)omap[os] : os, objs + o * OD, lane);
         }
         for (int k = lane; k < TW * acc_stride; k += 64) rows[k] = 0.0;
+        if constexpr (OBJK) {
+            const int64_t os = i0 < N ? i0 : N - 1;
+            const int nb = __builtin_amdgcn_readfirstlane(__popc(src.ov.bits[omap ? (int64_t)omap[os] : os]));   // observed bands (pad bits are 0)
+            wpr = nb - (SRC::LMODE == 2 ? 3 : 2);
+            // power 0 (two observed bands; three with the free scale): L = e^{-chi2/2} / C, largest at chi2 = 0 -- still bounded by its
+            // value at the mode, so the same scheme holds with K = 0.  Below that the likelihood is unbounded at chi2 -> 0: the sweep.
+            kok = wpr >= 0;
+            if (!kok) wpr = 1;                                          // (arithmetic stays finite; the object goes to the sweep)
+            K = uniform_d((double)wpr);                                 // (wave-uniform: scalar registers)
+            T0 = (wpr > 0) ? uniform_f((float)(-0.5 * K * log2(K))) : 0.f;
+            halfk = uniform_f(0.5f * (float)K);
+            lgq = uniform_d(src.lp.lgtab[nb]);
+            lref = uniform_d(lnl_c2(K));
+        }
         nl_stage_tile<SRC, TILE, NT, true>(src, posw, 0, tileA, tid, wave);
         __syncthreads();
         // the wave's objects stay in VGPRs for the whole model loop (an LDS broadcast read: the compiler
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 const float tm = EXACT ? 0.f : wave_maxf(hs.tmax[o]);
                 // no candidate at all, an evidence that is not a number, or a best weight so far below the mode
                 // that the fp32 remainder has lost terms (2^-126 / 2^-80: still 2^-46 below the best): the exact ln-space sweep decides
-                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f)) && hs.namb[o] >= 0;
+                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f)) && hs.namb[o] >= 0 && kok;
                 // the ambiguous band, by the reference's own rule (pdf.py:591) with the exact maximum and evidence
                 const int na = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                 if (na > 0) {

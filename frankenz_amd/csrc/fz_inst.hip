@@ -89,6 +89,25 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
 #endif
+#if !defined(FZ_DEV_FAST)
+    if (var == VAR_OBJMASK) {
+        // objects with unobserved bands against unmasked models, modes Ai / B: k_hist with per-object band counts on the mask-free
+        // arithmetic (the handed-back objects are swept by the masked variant); +1: not applicable, the caller takes the masked route
+        int r = 1;
+        switch (mode) {
+            case 1: { PhotSrc<FZ_BT, 1, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, 1, dim_prior);
+                      PhotSrc<FZ_BT, 1, VAR_MASKED> pm; pm.mv = ph.mv; pm.ov = ph.ov; pm.lp = ph.lp;
+                      r = fz_launch_hist_objmask(c, ph, pm, n, M, ko, lmap, levid, pdfs); } break;
+            case 2: { PhotSrc<FZ_BT, 2, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, 2, dim_prior);
+                      PhotSrc<FZ_BT, 2, VAR_MASKED> pm; pm.mv = ph.mv; pm.ov = ph.ov; pm.lp = ph.lp;
+                      r = fz_launch_hist_objmask(c, ph, pm, n, M, ko, lmap, levid, pdfs); } break;
+            default: break;
+        }
+        return r < 0 ? r : (r == 0 ? 0 : 1);
+    }
+#else
+    if (var == VAR_OBJMASK) return 1;
+#endif
 #if !FZ_EXACT_BT
     // 9-32 bands without a masked REAL band on tame data: the one-pass histogram kernel in its mask-free form (fz_hist.h: the pad
     // bands up to 16 / 32 are zeros, the power of chi2 follows the real band count); every other case of these band counts --

@@ -393,11 +393,13 @@ int fz_launch_nolist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
 
 // single pass with in-kernel LDS histograms and no candidate lists (fz_hist.h); +1 = not applicable / does not fit.
 // exact: every weight in fp64 (the all-fp64 evidence, and the form for broad likelihoods)
-template <class SRC, int TW, int NW, bool EXACT, bool SCRB>
+// OBJK / SWS: per-object band counts (fz_hist.h); the sweep over handed-back objects then runs on `sws`, the MASKED variant of
+// the same likelihood when objects may have unobserved bands (the mask-free arithmetic of `src` does not know N_dim per object)
+template <class SRC, int TW, int NW, bool EXACT, bool SCRB, bool OBJK = (SRC::NB > 8), class SWS = SRC>
 int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
-                     double* lmap, double* levid, double* pdfs) {
+                     double* lmap, double* levid, double* pdfs, const SWS* swsp = nullptr) {
     constexpr int SW = 4;
-    auto kern = fz::k_hist<SRC, TW, NW, EXACT, SCRB>;
+    auto kern = fz::k_hist<SRC, TW, NW, EXACT, SCRB, OBJK>;
     const size_t lds = (size_t)NW * TW * kv.acc_stride * 8;
     {
         hipFuncAttributes fa;
@@ -424,7 +426,25 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
         else if (fit >= c->cu_count / 2) blocks = fit;
         else return 1;
     } else if (fit < need) return 1;
-    const size_t sweep_ws = (size_t)c->cu_count * SW * M * sizeof(fz::Cand);
+    // the sweep over handed-back objects (exact ln-space body, candidate lists of M entries per wave): as many blocks as stay
+    // resident and fit the workspace (with per-object band counts a few per cent of a chunk can land there), at least one per CU
+    auto sweep = fz::k_fused<SWS, 1, SW, false, true>;
+    constexpr size_t TDB2 = (size_t)SWS::template tile_doubles<SWS::template tile_len<SW>()>();
+    const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+    bool sweep_ok = false;
+    int bps = 1;
+    {
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
+        if (fa.sharedSizeBytes + lds2 <= 160 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bps, (const void*)sweep, SW * 64, lds2));
+            sweep_ok = true;
+        }
+    }
+    const size_t sweep_blk = (size_t)SW * M * sizeof(fz::Cand);
+    bps = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(bps, 4), (int64_t)(c->ws_limit / (sweep_blk * c->cu_count))));
+    const size_t sweep_ws = (size_t)bps * c->cu_count * sweep_blk;
     if (c->d_cand.ensure(std::max((size_t)blocks * NW * per_wave, sweep_ws)) != 0) return 1;
     FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
@@ -434,19 +454,12 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
                        (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), acap, lmap, levid, pdfs, c->omap, c->d_redo.as<int>());
-    {
-        // sweep: the exact ln-space body over the objects handed back (count on the device)
-        auto sweep = fz::k_fused<SRC, 1, SW, false, true>;
-        constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
-        const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
-        hipFuncAttributes fa;
-        HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
-        if (fa.sharedSizeBytes + lds2 <= 160 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>(c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, src,
-                               c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
-                               lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
-        }
+    if (sweep_ok) {
+        SWS sws;
+        if constexpr (std::is_same<SWS, SRC>::value) sws = src; else sws = *swsp;
+        hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>((int64_t)bps * c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, sws,
+                           c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
+                           lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -485,6 +498,29 @@ int fz_launch_hist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, 
             if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             return fz_launch_hist_g<SRC, 2, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         }
+    }
+}
+
+// k_hist with per-object band counts or nothing (+1): a chunk whose objects have unobserved bands, unmasked models, modes Ai / B
+// (4-8 bands; the wide sets take this form anyway).  `src`: the mask-free variant, `sws`: the masked one (sweep).
+template <class SRC, class SWS>
+int fz_launch_hist_objmask(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap, double* levid,
+                           double* pdfs) {
+    if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 30) || SRC::LMODE == 0) return 1;
+    else {
+        fz::KdeView kv;
+        FZCHK(fz_kde_view(c, kv));
+        if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_OBJMASK") && atoi(getenv("FZ_HIST_OBJMASK")) == 0)) return 1;
+        const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
+        if (exact || !src.lp.dim_prior || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
+        fz_exact_now() = false;
+        constexpr bool SB = (SRC::LMODE == 2);
+        constexpr int NWH = SRC::NB > 8 ? 8 : 16;
+        int r;
+        if (SB && !getenv("FZ_HIST_NOSCRB")) r = fz_launch_hist_g<SRC, 1, NWH, false, SB, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
+        else r = fz_launch_hist_g<SRC, 1, NWH, false, false, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
+        if (r <= 0) c->last_form = "k_hist<screen> (per-object band counts)";
+        return r;
     }
 }
 

@@ -1025,3 +1025,45 @@ def test_wide_and_grid_switches_do_not_change_results(monkeypatch):
     u0, _ = rung(bent)
     ru, _, _ = fo.bruteforce_fit_predict(X[:40].copy(), Xe[:40].copy(), Xm[:40].copy(), Y, Ye, Ym, z, ze, label_grid=bent)
     close(u0[:40], ru, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
+@pytest.mark.parametrize('B', [5, 8, 12])
+def test_objects_with_unobserved_bands_on_the_one_pass_kernel(B, kw, monkeypatch):
+    """Objects with unobserved bands against unmasked models (every real catalogue), modes A with band-constant errors / Ai / B: the
+    one-pass kernel runs its mask-free arithmetic with the power of chi2 taken from each object's observed band count (a masked
+    band carries inverse variance 0 and adds exactly nothing); objects left with too few bands for a bounded likelihood (one
+    band; two with the free scale) are swept by the masked kernels.  Against the oracle, and against the split launches."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(4000 + B)
+    M, N = 2300, 420
+    sig = rs.uniform(0.3, 2.0, B)
+    Y = rs.lognormal(1., 1., size=(M, 1)) * rs.lognormal(0., .5, size=(M, B)); Ye = np.tile(0.3 * sig, (M, 1)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] * rs.lognormal(0, .1, N)[:, None] + sig * rs.randn(N, B); Xe = np.tile(sig, (N, 1))
+    Xm = (rs.uniform(size=(N, B)) > 0.25).astype(float)
+    for i, nobs in enumerate(range(B + 1)):                       # 0 ... B observed bands, explicitly
+        Xm[i] = 0.0; Xm[i, :nobs] = 1.0
+    X[Xm == 0] = 1e6                                              # garbage in the unobserved bands must not matter
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
+    with np.errstate(all='ignore'):
+        p0, (lm0, le0) = run()
+        if not (B == 8 and kw.get('free_scale')):                      # (8 bands with the free scale: the buffers of the closed-form screen do not fit the LDS beside 16 histogram rows)
+            assert get_engine().last_form() == 'k_hist<screen> (per-object band counts)'
+        monkeypatch.setenv('FZ_HIST_OBJMASK', '0')
+        p1, (lm1, le1) = run()
+        assert get_engine().last_form() != 'k_hist<screen> (per-object band counts)'
+        monkeypatch.delenv('FZ_HIST_OBJMASK')
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    # one observed band with the free scale: zero degrees of freedom, ln-like = (+-inf or a rounding-sized log) - gammaln(0): nan or
+    # -inf depending on whether the residual of the perfect fit rounds to exactly 0 (NumPy here: nan; the fma residual: -inf);
+    # the PDF row is nan either way
+    ok = np.ones(N, bool)
+    if kw.get('free_scale'):
+        ok[Xm.sum(axis=1) <= 1] = False
+        assert np.all(~np.isfinite(lm0[~ok])) and np.all(~np.isfinite(rlm[~ok]))
+    close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0[ok], rlm[ok], rtol=1e-9); close(le0[ok], rle[ok], **EVID)
+    close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)
