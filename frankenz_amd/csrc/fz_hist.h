@@ -121,7 +121,7 @@ template <class SRC>
 constexpr int hist_tile() {
     // 16 waves per block (up to 8 bands): 256-model tiles up to 10 doubles per record, 128 beyond (6-8 bands with per-model errors:
     // 14-18 doubles); 8 waves per block (the wide instantiations): 256 up to 18 doubles, 128 up to 34, 64 beyond
-    if (SRC::NB <= 8) return SRC::RW <= 10 ? 256 : 128;
+    if (SRC::NB <= 8) return (SRC::RW <= 10 && !(SRC::LMODE == 2 && SRC::RW > 6)) ? 256 : 128;   // (free scale at 7 / 8 bands: the model-number buffer is twice the size)
     return SRC::RW <= 18 ? 256 : (SRC::RW <= 34 ? 128 : 64);
 }
 // wide records: the next step's model record is NOT requested ahead where a second copy of the record does not fit the
