@@ -252,15 +252,20 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         if constexpr (OBJK) {
             const int64_t os = i0 < N ? i0 : N - 1;
             const int nb = __builtin_amdgcn_readfirstlane(__popc(src.ov.bits[omap ? (int64_t)omap[os] : os]));   // observed bands (pad bits are 0)
+            const int64_t oi = omap ? (int64_t)omap[os] : os;
             wpr = nb - (SRC::LMODE == 2 ? 3 : 2);
             // power 0 (two observed bands; three with the free scale): L = e^{-chi2/2} / C, largest at chi2 = 0 -- still bounded by its
             // value at the mode, so the same scheme holds with K = 0.  Below that the likelihood is unbounded at chi2 -> 0: the sweep.
             kok = wpr >= 0;
             if (!kok) wpr = 1;                                          // (arithmetic stays finite; the object goes to the sweep)
+            // without the dimensionality prior (pdf.py:94-98, 230-235) the likelihood IS the power-0 form for every band count:
+            // ln L = -chi2 / 2 - (N_dim ln 2 pi + sum ln var) / 2, the second term a constant of the object in modes Ai / B
+            const bool dp = src.lp.dim_prior != 0;
+            if (!dp) { wpr = 0; kok = true; }
             K = uniform_d((double)wpr);                                 // (wave-uniform: scalar registers)
             T0 = (wpr > 0) ? uniform_f((float)(-0.5 * K * log2(K))) : 0.f;
             halfk = uniform_f(0.5f * (float)K);
-            lgq = uniform_d(src.lp.lgtab[nb]);
+            lgq = uniform_d(dp ? src.lp.lgtab[nb] : 0.5 * ((double)nb * FZ_LN2PI + src.ov.slv[oi]));
             lref = uniform_d(lnl_c2(K));
         }
         nl_stage_tile<SRC, TILE, NT, true>(src, posw, 0, tileA, tid, wave);

@@ -90,7 +90,9 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
 #endif
 #if !defined(FZ_DEV_FAST)
-    if (var == VAR_OBJMASK) {
+    // (also: no dimensionality prior on mask-free data in modes Ai / B -- the power-0 form of the same kernel, pdf.py:94-98)
+    const bool nodp_fast = !dim_prior && (var == VAR_FAST || var == VAR_PAD) && (mode == 1 || mode == 2) && !c->prior.tab;
+    if (var == VAR_OBJMASK || nodp_fast) {
         // objects with unobserved bands against unmasked models, modes Ai / B: k_hist with per-object band counts on the mask-free
         // arithmetic (the handed-back objects are swept by the masked variant); +1: not applicable, the caller takes the masked route
         int r = 1;
@@ -103,7 +105,8 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
                       r = fz_launch_hist_objmask(c, ph, pm, n, M, ko, lmap, levid, pdfs); } break;
             default: break;
         }
-        return r < 0 ? r : (r == 0 ? 0 : 1);
+        if (var == VAR_OBJMASK) return r < 0 ? r : (r == 0 ? 0 : 1);
+        if (r <= 0) return r;
     }
 #else
     if (var == VAR_OBJMASK) return 1;

@@ -512,7 +512,8 @@ int fz_launch_hist_objmask(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n,
         FZCHK(fz_kde_view(c, kv));
         if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_OBJMASK") && atoi(getenv("FZ_HIST_OBJMASK")) == 0)) return 1;
         const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
-        if (exact || !src.lp.dim_prior || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
+        if (exact || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
+        if (!src.lp.dim_prior && getenv("FZ_HIST_NODIMPRIOR") && atoi(getenv("FZ_HIST_NODIMPRIOR")) == 0) return 1;
         fz_exact_now() = false;
         constexpr bool SB = (SRC::LMODE == 2);
         constexpr int NWH = SRC::NB > 8 ? 8 : 16;
