@@ -1067,3 +1067,30 @@ def test_objects_with_unobserved_bands_on_the_one_pass_kernel(B, kw, monkeypatch
         assert np.all(~np.isfinite(lm0[~ok])) and np.all(~np.isfinite(rlm[~ok]))
     close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0[ok], rlm[ok], rtol=1e-9); close(le0[ok], rle[ok], **EVID)
     close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)
+
+
+@pytest.mark.parametrize('kw', [{'dim_prior': False, 'ignore_model_err': True}, {'dim_prior': False, 'free_scale': True, 'ignore_model_err': True}])
+def test_no_dimensionality_prior_on_the_power_zero_form(kw, monkeypatch):
+    """dim_prior=False in modes Ai / B is the one-pass kernel's power-0 form (ln L = -chi2/2 - a constant of the object, pdf.py:94-98):
+    same answers as k_fused's ln-space body (FZ_HIST_NODIMPRIOR=0) and the oracle, with and without unobserved bands."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(55)
+    M, N, B = 1900, 500, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = np.tile(0.5 * SDSS5, (M, 1)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    for Xm in (np.ones((N, B)), (rs.uniform(size=(N, B)) > 0.2).astype(float)):
+        bf = BruteForce(Y, Ye, Ym)
+        run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
+        with np.errstate(all='ignore'):
+            p0, (lm0, le0) = run()
+            assert get_engine().last_form().startswith('k_hist<screen>')
+            monkeypatch.setenv('FZ_HIST_NODIMPRIOR', '0'); monkeypatch.setenv('FZ_HIST_OBJMASK', '0')
+            p1, (lm1, le1) = run()
+            assert not get_engine().last_form().startswith('k_hist')
+            monkeypatch.delenv('FZ_HIST_NODIMPRIOR'); monkeypatch.delenv('FZ_HIST_OBJMASK')
+            rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+        close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0, rlm, rtol=1e-9); close(le0, rle, **EVID)
+        close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)
