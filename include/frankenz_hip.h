@@ -87,8 +87,8 @@ void fz_ctx_destroy(fz_ctx* ctx);
 int  fz_sync(fz_ctx* ctx);
 int  fz_timing_reset(fz_ctx* ctx);
 int  fz_timing_get(fz_ctx* ctx, fz_timing* out);
-/* which kernel form the last fused fit_predict launch took ("k_hist<screen>", "k_hist<exact>", "k_fused",
- * "k_stats + k_kde", ...): the choice depends on the data (likelihood mode, masks, label errors, how broad the
+/* which kernel form the last fused fit_predict / predict launch took ("k_hist<screen>", "k_hist<screen> (per-object band
+ * counts)", "k_hist<exact>", "k_fused", "k_plane_rows", "k_plane_fused", "k_stats + k_kde", ...): the choice depends on the data (likelihood mode, masks, label errors, how broad the
  * likelihoods are), and a measurement should say what it measured.  No reference counterpart. */
 const char* fz_last_form(fz_ctx* ctx);
 /* byte budget for internal work space (candidate lists of the single-pass kernel, (N x M)
