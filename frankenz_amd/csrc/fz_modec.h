@@ -65,15 +65,22 @@ struct ModeC {
             double rv[BT], y[BT], x[BT];
             double inter = 0.0; shape = 0.0;
             double vprod = 1.0; int vexp = 0;
+            // the model's record (fluxes, squared errors: 2 BT doubles in one 16-byte-aligned row of the array-of-records copy) in
+            // BT 16-byte loads instead of 2 BT 8-byte ones from the band-major arrays: the record is re-read from L2 on every
+            // iteration (it does not fit registers beside the other models of the thread), half the load instructions
+            constexpr int RW0 = 2 * BT + ((6 - (2 * BT) % 4) % 4);
+            double rec[RW0];
+            {
+                const double2* rp = reinterpret_cast<const double2*>(mv.rec0) + (uint32_t)j * (uint32_t)(RW0 / 2);
+#pragma unroll
+                for (int q = 0; q < RW0 / 2; ++q) { const double2 w = rp[q]; rec[2 * q] = w.x; rec[2 * q + 1] = w.y; }
+            }
+            const double s2 = sprev * sprev;
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
-                // uniform base + 32-bit lane offset (the saddr form of the load): per-(band, model) 64-bit addresses, hoisted out of
-                // the iteration loop by the compiler, spilled the persistent kernel's state
-                const uint32_t jo = (uint32_t)j;
-                y[b] = (mv.y + (int64_t)b * mv.Mp)[jo];
+                y[b] = rec[b];
                 x[b] = ov.x[i * BT + b];
-                const double sye = sprev * (mv.ye + (int64_t)b * mv.Mp)[jo];
-                const double var = fma(sye, sye, ov.v[i * BT + b]);          // xe^2 + (s*ye)^2
+                const double var = fma(s2, rec[BT + b], ov.v[i * BT + b]);   // xe^2 + s^2 ye^2
                 rv[b] = rcp_nr<2>(var);
                 const double yr = y[b] * rv[b];
                 inter = fma(yr, x[b], inter);
