@@ -56,9 +56,16 @@ struct ModeC {
 
     // one solve of (scale, chi2, lnl) for variance var_b = xe2_b + (s_prev*ye_b)^2;
     // s_prev = 1 gives the initial pass of pdf.py:171-194.
+    static constexpr int REC_W = 2 * BT + ((6 - (2 * BT) % 4) % 4);       // doubles per row of the array-of-records copy (fluxes | squared errors | pad)
+    __device__ __forceinline__ void load_rec(int64_t j, double (&rec)[REC_W]) const {
+        const double2* rp = reinterpret_cast<const double2*>(mv.rec0) + (uint32_t)j * (uint32_t)(REC_W / 2);
+#pragma unroll
+        for (int q = 0; q < REC_W / 2; ++q) { const double2 w = rp[q]; rec[2 * q] = w.x; rec[2 * q + 1] = w.y; }
+    }
+    // lt: the 2 KB log table in LDS (k_modec_persist), or nullptr: the global copy
     template <bool FAST = false>
     __device__ __forceinline__ void solve(int64_t i, int64_t j, double sprev, double& s, double& lnl,
-                                          double& chi2, double& shape, int& ndim) const {
+                                          double& chi2, double& shape, int& ndim, const double2* lt = nullptr) const {
         if constexpr (FAST && !MASKED) {
             if (sub.nbr) j = sub.nbr[i * sub.W + j];
             ndim = nband;
@@ -68,13 +75,9 @@ struct ModeC {
             // the model's record (fluxes, squared errors: 2 BT doubles in one 16-byte-aligned row of the array-of-records copy) in
             // BT 16-byte loads instead of 2 BT 8-byte ones from the band-major arrays: the record is re-read from L2 on every
             // iteration (it does not fit registers beside the other models of the thread), half the load instructions
-            constexpr int RW0 = 2 * BT + ((6 - (2 * BT) % 4) % 4);
+            constexpr int RW0 = REC_W;
             double rec[RW0];
-            {
-                const double2* rp = reinterpret_cast<const double2*>(mv.rec0) + (uint32_t)j * (uint32_t)(RW0 / 2);
-#pragma unroll
-                for (int q = 0; q < RW0 / 2; ++q) { const double2 w = rp[q]; rec[2 * q] = w.x; rec[2 * q + 1] = w.y; }
-            }
+            load_rec(j, rec);
             const double s2 = sprev * sprev;
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
@@ -94,7 +97,9 @@ struct ModeC {
                 const double d = fma(-s, y[b], x[b]);
                 chi2 = fma(d * d, rv[b], chi2);
             }
-            const double slog = log_pos(vprod, global_tabs()) + (double)vexp * FZ_LN2;
+            FastTabs tl = global_tabs();
+            if (lt) tl.logt = lt;
+            const double slog = log_pos(vprod, tl) + (double)vexp * FZ_LN2;
             lnl = -0.5 * chi2 - 0.5 * ((double)ndim * FZ_LN2PI + slog);
             return;
         }
@@ -194,7 +199,15 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
     extern __shared__ double s_old[];                     // [M] the scale every model's last solve started from
     __shared__ double red[2][FZ_MCP_T / 64];
     __shared__ int s_flag[2];
+    // the log table (2 KB) in LDS: one table read per solve that would otherwise go to L2 beside the model record
+    __shared__ __attribute__((aligned(16))) double s_logt[FAST ? 256 : 2];
     const int tid = threadIdx.x;
+    const double2* lt = nullptr;
+    if constexpr (FAST) {
+        for (int k = tid; k < 256; k += FZ_MCP_T) s_logt[k] = FZ_LOG_TAB[k];
+        lt = reinterpret_cast<const double2*>(s_logt);
+        __syncthreads();
+    }
     for (int64_t slot = blockIdx.x; slot < Nc; slot += gridDim.x) {
         const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
         const int Mi = mc.sub.nnb ? (int)(mc.sub.nnb[i] < M ? mc.sub.nnb[i] : M) : M;
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
             sc[m] = 1.0; ll[m] = 0.0;
             if (j < Mi) {
                 double c, sh; int nd;
-                mc.template solve<FAST>(i, j, 1.0, sc[m], ll[m], c, sh, nd);
+                mc.template solve<FAST>(i, j, 1.0, sc[m], ll[m], c, sh, nd, lt);
                 s_old[j] = 1.0;
             }
         }
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
             asm volatile("" : "+v"(j));                  // re-formed per use: every (model, array) address kept live across the iteration loop spills the state
                 if (j < Mi) {
                     double sn, ln, c, sh; int nd;
-                    mc.template solve<FAST>(i, j, sc[m], sn, ln, c, sh, nd);
+                    mc.template solve<FAST>(i, j, sc[m], sn, ln, c, sh, nd, lt);
                     double ej = fabs(ln - ll[m]);
                     if (j == 0 && ej != ej) fnan = 1;
                     double ehj = ej;
