@@ -72,6 +72,7 @@ struct fz_ctx {
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
     bool models_masked = false, models_real_masked = false, models_wild = false, models_err_const = false;
+    int mc_lnl_only = 0;           // mode C: the caller of run_modec wants the final ln-like plane only (request); set back to 0 by whoever cannot honour it
     double grid_step = 0.0;        // gauss_kde grid labels: spacing of an evenly spaced grid (checked on upload), else 0
     DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1, d_ye2c;
     // kde dictionary (PDFDict)

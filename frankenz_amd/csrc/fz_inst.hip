@@ -145,6 +145,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     if (n > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.errhi = st.err + n; st.firstnan = c->d_mcfn.as<int>();
+    st.lnl_only = 0; st.lgtab = c->d_lgB.as<double>();
     // Active-object lists and their lengths live on the device and alternate between two slots; the host
     // queues FZ_MODEC_BURST iterations (step + stop rule, launched for the object count it last saw: blocks
     // of objects that stopped since exit at once) before it looks at the count again, so the loop is not
@@ -165,7 +166,10 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     const int burst = getenv("FZ_MODEC_BURST") ? std::max(1, atoi(getenv("FZ_MODEC_BURST"))) : 8;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
     int it_max = 0;
+    const int want_lnl_only = c->mc_lnl_only;
+    c->mc_lnl_only = 0;                                  // honoured below by the one-block-per-object path only (and not for neighbour subsets)
     if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
+        if (want_lnl_only && !sub.nbr && !getenv("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
         // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
         const size_t lds = (size_t)M * 8;
         auto launch = [&](auto kern, int T, const int* list, int64_t nobj) -> int {

@@ -41,6 +41,11 @@ struct ModeCState {
     int* amb;                  // FAST solve: objects whose error came within rounding of ltol (list), may be nullptr
     int* namb;                 // (1) their number
     int* ambflag;              // (Nc) already listed
+    // k_modec_persist only: the caller wants nothing but the final ln-like plane (fit_predict without stored fits) -- the converged
+    // object's rows of l are written in their final form (lnl_only = 1: as they are; 2: with the dimensionality prior, pdf.py:226-229)
+    // and s / c / sh are not written at all (three 8 B-per-pair planes and the k_modec_final pass less)
+    int lnl_only;
+    const double* lgtab;
 };
 
 // Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
@@ -274,10 +279,12 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
             int j = tid + m * FZ_MCP_T;
             asm volatile("" : "+v"(j));                  // re-formed per use: every (model, array) address kept live across the iteration loop spills the state
             if (j < Mi) {
+                const int64_t k = i * M + j;
+                if (st.lnl_only == 1) { st.l[k] = ll[m]; continue; }          // (the registers' ln-like IS that of the last solve)
                 double sn, ln, c, sh; int nd;
                 mc.template solve<FAST>(i, j, s_old[j], sn, ln, c, sh, nd);
-                const int64_t k = i * M + j;
-                st.s[k] = sn; st.l[k] = ln; st.c[k] = c; st.sh[k] = sh;
+                if (st.lnl_only) st.l[k] = chi2_logpdf<false>(0.5 * ((double)nd - 1.0) - 1.0, c, st.lgtab[nd], global_tabs());
+                else { st.s[k] = sn; st.l[k] = ln; st.c[k] = c; st.sh[k] = sh; }
             }
         }
         if (tid == 0) atomicMax(st.last_iter, iters);
