@@ -187,7 +187,7 @@ def main():
     strong = args.scaling == "strong" and world > 1
     sys.path.insert(0, ROOT)
     from frankenz_amd.sharded import shard_slice
-    do_gather = world > 1 and not args.no_gather and args.workload == "fit_predict"
+    do_gather = world > 1 and not args.no_gather and args.workload in ("fit_predict", "knn")
     if world > 1 and (strong or do_gather):
         # the SAME problem on every rank count: one seed; every rank holds the (small) full object arrays and the
         # library deals the objects out (sharded_fit_predict).  Weak scaling: --nobj objects per rank.
@@ -254,7 +254,7 @@ def main():
     d_le = torch.empty(N, dtype=torch.float64, device=dev)
     gathered = None
     bf = None
-    if do_gather:
+    if do_gather and args.workload == "fit_predict":
         # the library's multi-GPU call (drop-in class + sharded driver); the engine above is the same process-wide one
         from frankenz_amd import BruteForce, sharded
         os.environ["FRANKENZ_DEVICE"] = str(local)
@@ -282,10 +282,15 @@ def main():
         fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9))
         nn = NearestNeighbors(Y, Ye, Ym, K=Kt, feature_map="luptitude", fmap_kwargs=fk,
                               rstate=np.random.RandomState(1), verbose=False)
-        eng.knn_upload_trees(np.stack([t.data for t in nn.KDTrees]))
+        nn._device = local
+        # knn.py:830-832 for every object, once (host RNG: the stream is NumPy's); the steps then run device-resident through the
+        # drop-in class: query features, neighbour table and PDFs never leave HBM
         q = nn._query_features(X, Xe, np.random.RandomState(2))
         dQ = torch.from_numpy(q).to(dev)
-        d_idx = torch.empty((N, Kt * kk), dtype=torch.int64, device=dev)
+        nn_prep = nn.prepare_fit_predict(z, ze, label_dict=pd, kde_kwargs={"wt_thresh": args.wt_thresh}, lprob_kwargs=kw, k=kk)
+        if do_gather:
+            from frankenz_amd import sharded
+            d_pdf = None
 
     if args.workload == "summarize":
         # pdf.pdfs_summarize on the PDFs of one fused pass (device-resident stack)
@@ -308,8 +313,16 @@ def main():
             eng.predict_logwt(d_lnl, ko, d_pdf, d_lm, d_le, n=N)
             return
         if args.workload == "knn":
-            eng.knn_query(dQ, kk, float("inf"), d_idx, n=N, lp_norm=2)
-            eng.knn_fit_predict(dX, dXe, dXm, d_idx, Kt * kk, opts, ko, pdfs=d_pdf, lmap=d_lm, levid=d_le, n=N)
+            if do_gather:
+                # N > 1: ONE shared problem, objects dealt out block-cyclically, PDF rows gathered in place behind the next round's search
+                res = sharded.sharded_fit_predict(nn, dX, dXe, dXm, z, ze, gather='pdfs', chunks=args.chunks, label_dict=pd,
+                                                  lprob_kwargs=kw, kde_kwargs={"wt_thresh": args.wt_thresh}, save_fits=False,
+                                                  prepared=nn_prep, query_features=dQ, k=kk)
+                last[0] = res
+                st = sharded.last_stats
+                split[0] += st["ms_compute"] * 1e-3; split[1] += st["ms_gather_exposed"] * 1e-3
+                return
+            nn_prep.run(dX, dXe, dXm, out=(d_pdf, d_lm, d_le), query_features=dQ)      # NearestNeighbors.fit_predict(save_fits=False), device-resident
             return
         if bf is not None:
             # N > 1: shard compute + the overlapped RCCL all-gather of the PDF rows, as one library call
@@ -353,7 +366,7 @@ def main():
 
     # sanity: PDFs are normalised
     ok = True
-    if bf is not None:
+    if last[0] is not None:
         d_pdf = last[0][0]
         N_chk = int(d_pdf.shape[0])
         assert N_chk == N_total
@@ -405,8 +418,15 @@ def main():
                               "search_evals_per_s": 25.0 * N_total * M * args.steps / dt, "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "kernel_ms_per_step": tm["ms_knn"] / args.steps, "pdfs_normalised": ok,
-                              "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "NearestNeighbors.fit_predict: %d objects x %d models, K=25 k=20" % (N, M)}}))
+                              "dtype": "f64 (fp32 MFMA screen of the search, every admitted distance re-checked in fp64)", "data": "synthetic",
+                              "scaling": "strong" if (strong or world == 1) else "weak",
+                              "ms_compute": (split[0] / args.steps * 1e3) if do_gather else None,
+                              "ms_gather_exposed": (split[1] / args.steps * 1e3) if do_gather else None,
+                              "gather": ({"library_call": "frankenz_amd.sharded.sharded_fit_predict (NearestNeighbors, block-cyclic rounds, in-place all-gather)",
+                                          "rounds": sharded.last_stats.get("chunks"), "bytes_total": N_total * G * 8,
+                                          "ms_fence": sharded.last_stats.get("ms_fence")} if do_gather else None),
+                              "config": {"workload": "BASELINE configs[3] slice: NearestNeighbors.fit_predict(save_fits=False, device-resident): %d objects x %d models, "
+                                                     "K=25 k=20%s" % (N_total, M, (" sharded over %d GPUs (object axis)" % world) if world > 1 else "")}}))
 
     if rank == 0 and args.workload == "fit_predict":
         evals = float(N_total) * M * args.steps
@@ -443,10 +463,11 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
-            "dtype": ("f64 throughout (chi2, ln-likes, every weight, ln-evidence, PDFs)" if exact or "exact" in form else
+            "dtype": ("f64 throughout (chi2, ln-likes, every weight, ln-evidence, PDFs; an fp32 estimate of the weight only CLASSIFIES which "
+                      "pairs can matter to an fp64 sum, DESIGN.md 3.1)" if exact or form.startswith("k_hist") else
                       "f64 (chi2, ln-likes, PDFs and the weight of every model within wt_thresh of the best); the sum of the "
-                      "remaining sub-threshold weights in the ln-evidence runs in fp32 (DESIGN.md 3.1; roofline_fp64 is the "
-                      "all-fp64 form, lprob_kwargs={'exact_evidence': True})"),
+                      "remaining sub-threshold weights in the ln-evidence runs in fp32 on this kernel form (k_fused's weight-space "
+                      "body, DESIGN.md 3.1b; lprob_kwargs={'exact_evidence': True} gives the all-fp64 body)"),
             "data": "synthetic",
             "config": {"workload": "%s, BruteForce.fit_predict(save_fits=False), likelihood mode %s%s, %s" % (
                            what, args.mode, " (per-model errors)" if args.model_err == "varying" else "", kde_txt),
@@ -484,9 +505,9 @@ def main():
         if world == 1 and args.mode == "A" and args.model_err == "const" and not args.prior and args.mask_frac == 0 \
                 and args.kde == "dict" and args.label_err == "const" and args.noise_scale == 1.0 and not exact \
                 and not os.environ.get("FZ_BENCH_NO_EXTRA"):
-            # the headline configuration has band-constant model errors (the easy case of mode A) and an fp32 remainder in the
-            # evidence: the same workload (a) all-fp64, (b) on the GENERAL mode A kernels (per-model errors) and (c) with the free
-            # scale (mode B), two steps each, so that the driver's record holds the cases real data run on
+            # the headline configuration has band-constant model errors (the easy case of mode A): the same workload (a) on the GENERAL
+            # mode A kernels (per-model errors) and (b) with the free scale (mode B), two steps each, so that the driver's record holds
+            # the cases real data run on.  (Every one of them is fp64 throughout since round 4: there is no separate all-fp64 line.)
             def extra(Ye2, kw2, mode2):
                 eng.upload_models(Y, Ye2, Ym)
                 eng.set_labels(z, ze, label_dict=pd)               # labels belong to the model set they were uploaded with
@@ -504,8 +525,8 @@ def main():
                 a2 = N * M / (max(tm2["n_fused"], 1) / 2) * fl / (ms2 * 1e-3) / 1e12
                 return {"value": N * M / dt2, "unit": "evals/s", "ms_per_step": dt2 * 1e3, "achieved": a2, "peak": FP64_VALU_PEAK_TFLOPS,
                         "frac": a2 / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": fl, "avg_launch_ms": ms2, "kernel": eng.last_form()}
-            out["roofline_fp64"] = dict(extra(Ye, {"exact_evidence": True}, "A"),
-                                        note="the headline workload with every weight and the whole ln-evidence in fp64 (lprob_kwargs={'exact_evidence': True})")
+            out["roofline_fp64"] = dict(out["roofline"], value=value, ms_per_step=dt / args.steps * 1e3,
+                                        note="the headline line IS the all-fp64 form since round 4 (same numbers, kept under the old key)")
             out["roofline_general"] = dict(extra(Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape), {}, "A"),
                                            note="mode A with per-model errors (--model-err varying): the general kernels")
             out["roofline_modeB"] = dict(extra(Ye, MODES["B"], "B"), note="free scale, model errors ignored (--mode B)")

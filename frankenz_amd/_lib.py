@@ -50,6 +50,11 @@ ABI = {
     "fz_timing_get": (C.c_int, [_P, C.POINTER(Timing)]),
     "fz_last_form": (C.c_char_p, [_P]),
     "fz_set_workspace_limit": (C.c_int, [_P, _I64]),
+    "fz_set_producer_stream": (C.c_int, [_P, _P, _I32]),
+    "fz_host_alloc": (C.c_int, [_I64, C.POINTER(_P)]),
+    "fz_host_free": (C.c_int, [_P]),
+    "fz_modec_info": (C.c_int, [_P, _P]),
+    "fz_modec_niter": (C.c_int, [_P, _I64, _P]),
     "fz_models_upload": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
     "fz_kdedict_upload": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "fz_labels_upload_dict": (C.c_int, [_P, _P, _P, _I64]),
@@ -72,6 +77,8 @@ ABI = {
     "fz_pdfs_resample": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _F64, _F64, _I32, _P]),
     "fz_overlap_nz": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _F64, _P, _P]),
     "fz_nz_assign": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "fz_knn_search_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _F64, _F64, C.POINTER(LikeOpts),
+                                                  C.POINTER(KdeOpts), C.POINTER(Prior)] + [_P] * 12),
     "fz_knn_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),
                                            C.POINTER(KdeOpts), C.POINTER(Prior)] + [_P] * 12),
 }

@@ -23,7 +23,7 @@ import sys
 import numpy as np
 
 from . import pdf as _pdf
-from .engine import HostObjects, get_engine, kde_opts, like_opts, merge_kde_args
+from .engine import HostObjects, get_engine, kde_opts, like_opts, merge_kde_args, pinned_empty
 
 __all__ = ["BruteForce"]
 
@@ -80,13 +80,29 @@ class _Prepared(object):
     """A model set + labels resident on the device and the option structs of one ``fit_predict`` configuration
     (``BruteForce.prepare_fit_predict``)."""
 
-    def __init__(self, bf, eng, opts, ko, Nx, prior):
+    def __init__(self, bf, eng, opts, ko, Nx, prior, labels=None):
         self.bf, self.eng, self.opts, self.ko, self.Nx, self.prior = bf, eng, opts, ko, Nx, prior
+        # the engine is shared by every fitter of the process: what the device held when this handle was made
+        self._labels = labels
+        self._keys = (eng._models_key, eng._dict_key, eng._labels_key)
+
+    def _ensure_resident(self):
+        """another fitter, ``predict()`` or label upload may have used the engine since: put this handle's model set and
+        labels back (content keys make the check free when nothing changed)"""
+        eng = self.eng
+        if (eng._models_key, eng._dict_key, eng._labels_key) == self._keys:
+            return
+        if self._labels is None:
+            raise RuntimeError("the device no longer holds the model set / labels this handle was prepared with")
+        eng.upload_models(self.bf.models, self.bf.models_err, self.bf.models_mask)
+        eng.set_labels(*self._labels)
+        self._keys = (eng._models_key, eng._dict_key, eng._labels_key)
 
     def run(self, data, data_err, data_mask, out=None, save_fits=False, track_scale=False):
         """-> (pdfs, lmap, levid): ``out`` if given (float64, C-contiguous, NumPy or tensors on the engine's GPU), else fresh
         arrays of the kind ``data`` is.  Device tensors are cleaned in place by the library (pdf.py:310-311)."""
         bf, eng, Nx = self.bf, self.eng, self.Nx
+        self._ensure_resident()
         on_dev = hasattr(data, "data_ptr")
         Ndata = int(data.shape[0])
         bf._ndata_all = Ndata
@@ -97,7 +113,7 @@ class _Prepared(object):
                        torch.empty(Ndata, dtype=torch.float64, device=data.device),
                        torch.empty(Ndata, dtype=torch.float64, device=data.device))
             else:
-                out = (np.zeros((Ndata, Nx)), np.zeros(Ndata), np.zeros(Ndata))
+                out = (pinned_empty((Ndata, Nx)), np.zeros(Ndata), np.zeros(Ndata))
         pdfs, lmap, levid = out
         for a, shp in ((pdfs, (Ndata, Nx)), (lmap, (Ndata,)), (levid, (Ndata,))):
             if tuple(a.shape) != shp or str(a.dtype).split('.')[-1] != 'float64':
@@ -311,7 +327,7 @@ class BruteForce():
         lw = np.ascontiguousarray(logwt, dtype=np.float64)
         Ndata = self.NDATA if self.NDATA is not None else len(lw)
         _check_logwt(lw, Ndata, len(model_labels))
-        pdfs = np.zeros((Ndata, Nx))
+        pdfs = pinned_empty((Ndata, Nx))
         lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
         eng.predict_logwt(lw, ko, pdfs, lmap, levid, n=Ndata)
         _progress(verbose, 'Generating PDF', Ndata, Ndata)
@@ -390,7 +406,7 @@ class BruteForce():
         obj = HostObjects(data, data_err, data_mask)
         Ndata = len(obj.x)
         self._ndata_all = Ndata
-        pdfs = np.zeros((Ndata, Nx))
+        pdfs = pinned_empty((Ndata, Nx))         # every row is written by the library (the reference fills np.zeros row by row)
         lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
         if save_fits:
             self.NDATA = Ndata
@@ -422,7 +438,7 @@ class BruteForce():
         ko = kde_opts(kde_kwargs)
         eng = self._engine()
         Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
-        return _Prepared(self, eng, opts, ko, Nx, prior)
+        return _Prepared(self, eng, opts, ko, Nx, prior, labels=(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs))
 
     def _fit_predict_into(self, data, data_err, data_mask, model_labels, model_label_errs, label_dict, label_grid,
                           kde_kwargs, lprob_kwargs, prior, return_gof, track_scale, save_fits, out):

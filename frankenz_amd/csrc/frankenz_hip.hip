@@ -64,6 +64,7 @@ extern "C" void fz_ctx_destroy(fz_ctx* c) {
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_done[k]); (void)hipEventDestroy(c->ev_copied[k]); }
     if (c->ev_probe) (void)hipEventDestroy(c->ev_probe);
+    if (c->ev_producer) (void)hipEventDestroy(c->ev_producer);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
@@ -76,10 +77,42 @@ extern "C" int fz_sync(fz_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
-extern "C" int fz_timing_reset(fz_ctx* c) { if (!c) return fail(-1, "ctx is NULL"); c->tm = fz_timing{}; return 0; }
+extern "C" int fz_timing_reset(fz_ctx* c) { if (!c) return fail(-1, "ctx is NULL"); c->tm = fz_timing{}; for (auto& v : c->mc_info) v = 0; return 0; }
 extern "C" int fz_timing_get(fz_ctx* c, fz_timing* out) {
     if (!c || !out) return fail(-1, "fz_timing_get: NULL argument");
     *out = c->tm; return 0;
+}
+// page-locked host memory for results (the drop-in classes return PDFs in it: a device-to-host copy into pageable memory is
+// staged by the runtime and runs at a third of the link rate)
+extern "C" int fz_host_alloc(int64_t bytes, void** out) {
+    if (!out || bytes <= 0) return fail(-1, "fz_host_alloc: bad argument");
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(-2, "hipHostMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+extern "C" int fz_host_free(void* p) {
+    if (!p) return 0;
+    HIPCHK(hipHostFree(p));
+    return 0;
+}
+// mode C since the last fz_timing_reset: {objects re-run by the IEEE solve because their error came within rounding of ltol, iterations of the
+// slowest object, 1 = one block per object (k_modec_persist) / 2 = state planes (k_modec_step / _check), threads per block of the
+// persistent shape}
+extern "C" int fz_modec_info(fz_ctx* c, int64_t* out4) {
+    if (!c || !out4) return fail(-1, "fz_modec_info: NULL argument");
+    for (int k = 0; k < 4; ++k) out4[k] = c->mc_info[k];
+    return 0;
+}
+// iterations of pdf.py:199's loop each object of the LAST mode-C chunk took (the reference has no such output; tests compare it with
+// the restated loop's count): n <= the chunk's objects, out int32 (host)
+extern "C" int fz_modec_niter(fz_ctx* c, int64_t n, int32_t* out) {
+    if (!c || !out) return fail(-1, "fz_modec_niter: NULL argument");
+    if (n < 0 || n > c->mc_niter_n) return fail(-1, "fz_modec_niter: %lld objects asked, the last mode-C chunk held %lld", (long long)n, (long long)c->mc_niter_n);
+    if (!n) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    return copy_out(c, out, c->d_mcniter.p, (size_t)n * 4);
 }
 extern "C" int fz_set_workspace_limit(fz_ctx* c, int64_t bytes) {
     if (!c || bytes < (1 << 20)) return fail(-1, "fz_set_workspace_limit: need >= 1 MiB");
@@ -202,7 +235,7 @@ extern "C" int fz_kdedict_upload(fz_ctx* c, int64_t G, int64_t D, const int64_t*
     FZCHK(copy_in(c, c->d_widths.p, widths, D * 8));
     FZCHK(copy_in(c, c->d_offsets.p, offsets, (D + 1) * 8));
     FZCHK(copy_in(c, c->d_kern.p, kern, tot * 8));
-    c->G = G; c->D = D;
+    c->G = G; c->dict_G = G; c->D = D;
     c->label_mode = 0;
     return 0;
 }
@@ -221,7 +254,8 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     } else { memcpy(hy.data(), y_idx, M * 8); memcpy(hs.data(), y_std_idx, M * 8); }
     std::vector<int32_t> pos(Mp, 0), cls(Mp, 0);
     std::vector<double> nrm(Mp, 1.0);
-    const int64_t G = c->G;
+    // the grid length is the DICTIONARY's: fz_labels_upload_grid leaves its own grid's length in c->G
+    const int64_t G = c->G = c->dict_G;
     bool single = true;
     for (int64_t j = 0; j < M; ++j) {
         const int64_t d = hs[j], p = hy[j];
@@ -377,7 +411,10 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
         const double step = (hg[(size_t)G - 1] - hg[0]) / (double)(G - 1);
         bool even = step > 0.0 && (step - step == 0.0);
         for (int64_t t = 0; t < G && even; ++t) even = fabs(hg[(size_t)t] - (hg[0] + (double)t * step)) <= 1e-9 * step;
-        if (even) c->grid_step = step;
+        // (the recurrence seeds a window with e^{-z^2/2} and e^{-z h - h^2/2}, both clamped at e^{+-700}: with windows of more than ~30
+        //  label errors the seed point lies so far in the tail that the product of the two clamped values is O(1) instead of ~0 --
+        //  such calls keep the per-point exponential)
+        if (even && sig_thresh <= 30.0) c->grid_step = step;
     }
     FZCHK(c->d_lrec.ensure((size_t)Mp * 48));
     HIPCHK(hipMemsetAsync(c->d_lrec.p, 0, (size_t)Mp * 48, c->stream));
@@ -404,7 +441,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
 // vmode 0: v = xe^2 (modes A, C) ; 1: v = 1/xe^2 (modes Ai, B) ; 2: v = 1/(xe^2 + ye2c[b]) (mode A with
 // band-constant model errors, evaluated by the mode Ai kernels; slv = sum log(xe^2 + ye2c))
 // flags: bit0 some data mask is 0 after cleaning, bit1 some mask non-binary,
-// bit2 some value outside the fast arithmetic's range
+// bit2 some value outside the fast arithmetic's range, bit3 some entry was rewritten by the clean
 __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int B, int BT, int vmode,
                                int derive, double* ox, double* ov, uint32_t* bits, double* slv,
                                int* flags, const double* __restrict__ ye2c) {
@@ -416,7 +453,7 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
         if (b < B) {
             double f = x[i * B + b], e = xe[i * B + b], mk = xm[i * B + b];
             const bool clean = (f - f == 0.0) && (e - e == 0.0) && (e > 0.0);   // isfinite & isfinite & >0
-            if (!clean) { f = 0.0; e = 1.0; mk = 0.0; x[i * B + b] = f; xe[i * B + b] = e; xm[i * B + b] = mk; }
+            if (!clean) { f = 0.0; e = 1.0; mk = 0.0; x[i * B + b] = f; xe[i * B + b] = e; xm[i * B + b] = mk; fl |= 8; }
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
             const double e2 = (vmode == 2) ? e * e + ye2c[b] : e * e;       // pdf.py:77 tot_var
@@ -435,12 +472,32 @@ __global__ void k_prep_objects(double* x, double* xe, double* xm, int64_t N, int
 
 // Stream-ordering contract of the ABI (include/frankenz_hip.h): the library works on its own
 // non-blocking stream.  Arguments in device memory may have been produced by kernels the caller
-// queued on ANY stream, so every entry point that accepts device pointers first waits for the
-// device (hipDeviceSynchronize: ~10 us when idle), and returns only when its own work is done.
+// queued on ANY stream, so by default every entry point that accepts device pointers first waits
+// for the device (hipDeviceSynchronize: ~10 us when idle).  That wait also drains work that has
+// nothing to do with the call -- an RCCL all-gather of the previous round's rows in flight on
+// another stream -- so a caller that knows where its inputs come from says so
+// (fz_set_producer_stream): the library's stream then waits for an event recorded on THAT stream
+// (no host wait, nothing else drained), or for nothing at all when the caller has synchronised.
 static int wait_for_producers(fz_ctx* c, std::initializer_list<const void*> ptrs) {
-    (void)c;
+    bool dev = false;
     for (const void* p : ptrs)
-        if (is_device_ptr(p)) { HIPCHK(hipDeviceSynchronize()); break; }
+        if (is_device_ptr(p)) { dev = true; break; }
+    if (!dev) return 0;
+    if (c->producer_mode == 2) return 0;                          // inputs complete: the caller's word
+    if (c->producer_mode == 1) {
+        if (!c->ev_producer) HIPCHK(hipEventCreateWithFlags(&c->ev_producer, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_producer, c->producer_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_producer, 0));
+        return 0;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+extern "C" int fz_set_producer_stream(fz_ctx* c, void* stream, int32_t mode) {
+    if (!c) return fail(-1, "fz_set_producer_stream: ctx is NULL");
+    if (mode < 0 || mode > 2) return fail(-1, "fz_set_producer_stream: mode %d not in {0, 1, 2}", mode);
+    c->producer_mode = mode;
+    c->producer_stream = (mode == 1) ? (hipStream_t)stream : nullptr;
     return 0;
 }
 
@@ -485,6 +542,7 @@ extern "C" int fz_clean(fz_ctx* c, double* x, double* xe, double* xm, int64_t N,
     if (!c || !x || !xe || !xm) return fail(-1, "fz_clean: NULL argument");
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    FZCHK(wait_for_producers(c, {x, xe, xm}));
     const int sB = c->B, sBT = c->BT;
     c->B = B; c->BT = B;
     ObjChunk ch; int fl = 0; int r = 0;
@@ -582,7 +640,7 @@ static int modec_final(fz_ctx* c, int64_t n, bool masked, const fz_like_opts* o,
     SubsetView sub; sub.nbr = nbr; sub.nnb = nnb; sub.W = W;
     const int64_t Mloc = nbr ? W : c->M;
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
-    st.sh = c->d_mc[3].as<double>(); st.err = nullptr; st.firstnan = nullptr; st.list = nullptr; st.list_next = nullptr; st.nactive = nullptr; st.ncur = nullptr; st.last_iter = nullptr;
+    st.sh = c->d_mc[3].as<double>(); st.niter = nullptr; st.err = nullptr; st.firstnan = nullptr; st.list = nullptr; st.list_next = nullptr; st.nactive = nullptr; st.ncur = nullptr; st.last_iter = nullptr;
     const int64_t tot = n * Mloc;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
     hipLaunchKernelGGL(k_modec_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, st, model_view(c), sub,
@@ -753,6 +811,8 @@ extern "C" int fz_fit_predict(fz_ctx* c, double* x, double* xe, double* xm, int6
                               const fz_kde_opts* ko, double* pdfs, double* lmap, double* levid) {
     return fz_fit_predict_prior(c, x, xe, xm, N, o, ko, nullptr, pdfs, lmap, levid);
 }
+static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o,
+                            const fz_kde_opts* ko, const fz_prior* pr, double* pdfs, double* lmap, double* levid);
 extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o,
                                     const fz_kde_opts* ko, const fz_prior* pr, double* pdfs, double* lmap, double* levid) {
     if (!c || !x || !xe || !xm || !o || !pdfs) return fail(-1, "fz_fit_predict: NULL argument");
@@ -761,6 +821,36 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     if (N <= 0) return 0;
     HIPCHK(hipSetDevice(c->device));
     FZCHK(wait_for_producers(c, {x, xe, xm, pr ? pr->table : nullptr, pr ? pr->rows : nullptr}));
+    // Host objects: the whole (N, B) x 3 set goes to the device ONCE (120 MB at 1e6 x 5), is cleaned there, and comes back only if the
+    // clean changed anything -- staged chunk by chunk, every chunk's six small synchronous copies waited for the previous chunk's kernel
+    // and left the GPU idle meanwhile (~5 ms per chunk)
+    const size_t raw = (size_t)N * c->B * 8;
+    if (!is_device_ptr(x) && !is_device_ptr(xe) && !is_device_ptr(xm) && raw <= ((size_t)1 << 30) && N >= 4096) {
+        FZCHK(c->d_sx.ensure(raw)); FZCHK(c->d_sxe.ensure(raw)); FZCHK(c->d_sxm.ensure(raw));
+        HIPCHK(hipMemcpyAsync(c->d_sx.p, x, raw, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_sxe.p, xe, raw, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_sxm.p, xm, raw, hipMemcpyHostToDevice, c->stream));
+        FZCHK(c->d_flags.ensure(64));
+        HIPCHK(hipMemsetAsync(c->d_flags.p, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_prep_objects, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, c->d_sx.as<double>(), c->d_sxe.as<double>(),
+                           c->d_sxm.as<double>(), N, c->B, c->BT, 0, 0, (double*)nullptr, (double*)nullptr, (uint32_t*)nullptr, (double*)nullptr,
+                           c->d_flags.as<int>(), c->d_ye2c.as<double>());
+        HIPCHK(hipGetLastError());
+        int fl = 0;
+        FZCHK(copy_out(c, &fl, c->d_flags.p, sizeof fl));
+        if (fl & 2) return fail(-4, "data_mask must be binary (0/1)");
+        if (fl & 8) {                                            // pdf.py:310-311 rewrote something: the caller's arrays see it
+            FZCHK(copy_out(c, x, c->d_sx.p, raw)); FZCHK(copy_out(c, xe, c->d_sxe.p, raw)); FZCHK(copy_out(c, xm, c->d_sxm.p, raw));
+        }
+        const int pm = c->producer_mode; c->producer_mode = 2;    // the staged copies are this stream's own work
+        const int r = fit_predict_impl(c, c->d_sx.as<double>(), c->d_sxe.as<double>(), c->d_sxm.as<double>(), N, o, ko, pr, pdfs, lmap, levid);
+        c->producer_mode = pm;
+        return r;
+    }
+    return fit_predict_impl(c, x, xe, xm, N, o, ko, pr, pdfs, lmap, levid);
+}
+static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_t N, const fz_like_opts* o,
+                            const fz_kde_opts* ko, const fz_prior* pr, double* pdfs, double* lmap, double* levid) {
     const int mode = eff_mode(c, like_mode(o));
     const int64_t M = c->M, G = c->G;
     if (c->label_mode == 0) return fail(-1, "fz_fit_predict: labels have not been uploaded");
@@ -773,11 +863,11 @@ extern "C" int fz_fit_predict_prior(fz_ctx* c, double* x, double* xe, double* xm
     const int64_t per_obj = M * 8 * (mode == 3 ? 4 : (cdf ? 1 : 0)) + pb.chunk_bytes_per_obj;
     if (per_obj) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / per_obj));
     // Host PDFs are the bulk of the PCIe traffic of the drop-in call (5.6 GB at 1e6 objects, longer
-    // than the kernel).  Pipeline: chunks of 2^18 objects, two device staging buffers, chunk k's rows
+    // than the kernel).  Pipeline: chunks of 2^17 objects, two device staging buffers, chunk k's rows
     // leave on a second stream while chunk k+1 is being computed; kernel timing is deferred so that
     // the host does not wait on a kernel before it has queued the previous chunk's copy.
     const bool pipe = !pdf_dev && mode != 3 && !cdf && N >= (3 << 17) && !getenv("FZ_NO_PIPELINE");
-    if (pipe) nc = std::min<int64_t>(nc, 1 << 18);
+    if (pipe) nc = std::min<int64_t>(nc, 1 << 17);               // (the last chunk's rows leave with nothing to hide behind: keep it small)
     struct PipeGuard {
         fz_ctx* c; bool on;
         ~PipeGuard() { if (on) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); c->defer_timing = false; timer_flush(c); } }

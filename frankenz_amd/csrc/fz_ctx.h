@@ -51,6 +51,9 @@ struct fz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // where device-resident inputs come from (fz_set_producer_stream): 0 unknown -> device-wide wait, 1 `producer_stream` -> event wait,
+    // 2 already complete -> no wait
+    int producer_mode = 0; hipStream_t producer_stream = nullptr; hipEvent_t ev_producer = nullptr;
     // host-PDF pipeline of fit_predict: chunk k's rows leave on copy_stream while chunk k+1 is computed
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
@@ -72,11 +75,13 @@ struct fz_ctx {
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
     bool models_masked = false, models_real_masked = false, models_wild = false, models_err_const = false;
+    int64_t mc_info[4] = {0, 0, 0, 0};   // fz_modec_info: ambiguous objects re-run, slowest object's iterations, path, block shape
     int mc_lnl_only = 0;           // mode C: the caller of run_modec wants the final ln-like plane only (request); set back to 0 by whoever cannot honour it
     double grid_step = 0.0;        // gauss_kde grid labels: spacing of an evenly spaced grid (checked on upload), else 0
     DevBuf d_y, d_ye2, d_ye, d_mbits, d_lgA, d_lgB, d_rec0, d_rec1, d_ye2c;
     // kde dictionary (PDFDict)
-    int64_t G = 0, D = 0;
+    int64_t G = 0, D = 0;       // G: grid length of the labels in force (dictionary or direct grid)
+    int64_t dict_G = 0;         // grid length of the uploaded dictionary (restored by fz_labels_upload_dict)
     std::vector<int64_t> h_widths, h_offsets; std::vector<double> h_kcdf;
     DevBuf d_widths, d_offsets, d_kern;
     // labels
@@ -88,10 +93,11 @@ struct fz_ctx {
     bool mc_ok = false, mc_rec0_valid = false, mc_rec1_valid = false; int32_t mc_gp = 0, mc_w0 = 0;
     DevBuf d_mc_tag, d_mc_perm, d_mc_width, d_mc_off, d_mc_norm, d_rec0p, d_rec1p;
     // per-chunk object buffers
+    DevBuf d_sx, d_sxe, d_sxm;       // a host call's whole object set, staged once (fz_fit_predict)
     DevBuf d_rx, d_rxe, d_rxm, d_ox, d_ov, d_obits, d_oslv, d_flags;
     DevBuf d_lmap, d_levid, d_pdfs, d_pdfs2;
     DevBuf d_pl[7];            // staging planes
-    DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt;
+    DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt, d_mcniter; int64_t mc_niter_n = 0;
     DevBuf d_cand, d_kv, d_olstats;
     DevBuf d_sgrid, d_sloss;         // pdfs_summarize: grid / loss matrix   // candidate lists / KDE table view / per-object statistics of the single-pass kernels
     // additive ln-prior of the chunk being processed (tab == nullptr: none); set by bind_prior
@@ -102,14 +108,15 @@ struct fz_ctx {
     DevBuf d_nlmax;            // list-free form: chi2 of each object's best model
     DevBuf d_omap, d_redo;     // d_redo: objects the weight-space body hands to the ln-space body (count, then indices)
     // knn
-    int knn_K = 0, knn_F = 0; int64_t knn_M = 0; bool knn_mfma = false, knn_sorted = false;
+    int knn_K = 0, knn_F = 0; int64_t knn_M = 0; bool knn_mfma = false, knn_sorted = false, knn_kd = false;
+    DevBuf d_idxs;             // neighbour table of the chunk being searched and fitted (fz_knn_search_fit_predict)
     DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm, d_kbmat, d_kcen, d_kpmax, d_kperm, d_ktab, d_kbnd, d_kqperm, d_kqcnt;
 
     std::vector<DevBuf*> all_bufs() {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
-                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_rx, &d_rxe, &d_rxm, &d_ox,
+                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
-                                  &d_mcfn, &d_mcact, &d_mccnt, &d_cand, &d_kv, &d_olstats, &d_omap, &d_redo, &d_nlmax, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kbnd, &d_kqperm, &d_kqcnt};
+                                  &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_olstats, &d_omap, &d_redo, &d_nlmax, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kbnd, &d_kqperm, &d_kqcnt};
         for (auto& b : d_pl) v.push_back(&b);
         for (auto& b : d_mc) v.push_back(&b);
         return v;

@@ -24,15 +24,18 @@
 // exact weight, exact evidence share, best chi2 on either side of the mode (the exact maximum, as in
 // k_nl_max), histogram add or the ambiguous list.  The drain's latency overlaps the model loop of
 // the other waves instead of forming a phase of its own.
-// What is fp32: the screening weight and the sum of the NON-candidates (each below wt_thresh of the
-// running best) -- as in k_fused's weight-space body.  EXACT = true computes every pair's weight in
-// fp64 (the all-fp64 evidence; also the form for broad likelihoods, where most pairs are candidates).
+// What is fp32: ONLY the classifier.  t = log2 of the pair's weight, to ~1e-5, decides with a margin of 1 (a factor 2) whether the
+// pair can matter at all: a weight below 2^-(55 + ceil log2 M) of the best weight seen SO FAR (hence of the final best) is dropped --
+// all M of them together change the fp64 sum of the evidence by less than 2^-55 of it, a quarter of its last bit -- and every
+// other pair (41 % on the SDSS-depth benchmark, 7 % of them above wt_thresh) goes through the LDS buffer and gets its weight in
+// fp64, 64 at a time.  No fp32 term enters any sum: ln-evidence, ln-max, stacked weights and PDFs are the fp64 numbers of the
+// reference's logsumexp / exp / KDE (bruteforce.py:619-629) to fp64 rounding.  (Rounds 2-3 summed the pairs below wt_thresh of
+// the running best in fp32 -- 1e-9 on the ln-evidence, 6.3e11 evals/s against 4.9e11: gone, the reference is fp64 throughout.)
+// EXACT = true computes every pair's weight in fp64 without classifying (the form for broad likelihoods, where most pairs matter).
 //
-// Mode B (free scale): SCRB screens with the closed form chi2 = A - inter^2 / shape (A = sum x^2/var,
-// one reciprocal) and the drain re-evaluates the reference's residual form sum (x - s y)^2 / var
-// (pdf.py:188-189) from the model record -- the ring then carries the model number, and the label index
-// is read beside the record.  Every chi2 that reaches an output is the exact one; a training-set
-// self match still gives chi2 == 0 exactly.
+// Mode B (free scale) runs the EXACT form: its chi2 needs the scale first (two passes over the bands, pdf.py:181-189), the closed
+// form A - inter^2 / shape cancels at S/N^2 ~ 1e9 and could only screen -- with 41 % of the pairs then re-evaluated from a gathered
+// record that was slower (2.9e11 evals/s) than weighing every pair from the residual form directly (3.4e11).
 #pragma once
 #include <type_traits>
 #include "fz_kernels.h"
@@ -67,6 +70,16 @@ __device__ __forceinline__ double exp_small_tab(double x, const double* __restri
     return __hiloint2double(__double2hiint(v) + ((n >> 8) << 20), __double2loint(v));
 }
 
+// sqrt(r) for r > 0 from v_rsq_f64 (seed ~2^-24) with two coupled Newton steps on the ROOT itself (s += (r - s^2) y / 2: two
+// instructions each, quadratic: 2^-24 -> 2^-47 -> rounding); r == 0 (chi2 == 0, a self match) gives 0
+__device__ __forceinline__ double sqrt_nr(double r) {
+    const double y = __builtin_amdgcn_rsq(vmax_raw(r, 1e-300));
+    const double hy = 0.5 * y;
+    double s = r * y;
+    s = fma(fma(-s, s, r), hy, s);
+    s = fma(fma(-s, s, r), hy, s);
+    return s;
+}
 // w = L(chi2) / L(K) = (chi2 / K)^(K/2) exp(-(chi2 - K) / 2), all fp64: integer powers by multiplication,
 // the half power by a Newton-refined v_rsq_f64, one exp, no log
 template <int WP, bool SMALL = false>
@@ -84,13 +97,8 @@ __device__ __forceinline__ double hist_exactw(double c2, const FastTabs& tb) {
 #pragma unroll
         for (int e = WP >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }
     }
-    if constexpr (WP & 1) {
-        double y = __builtin_amdgcn_rsq(r);
-        y = y * fma(-0.5 * r, y * y, 1.5);
-        y = y * fma(-0.5 * r, y * y, 1.5);
-        pw = pw * ((r > 0.0) ? r * y : 0.0);              // chi2 == 0 (self match): weight 0
-    }
-    const double w = pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+    if constexpr (WP & 1) pw = pw * sqrt_nr(r);           // chi2 == 0 (self match): weight 0
+    const double w = pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
     // the exponential is clamped at e^-700, which a high power of a huge chi2 would lift back into range (r^15 reaches 1e300):
     // beyond the clamp the weight is zero, as in the reference's exp
     if constexpr ((WP >> 1) > 3) return (c2 < K + 1400.0) ? w : 0.0;
@@ -106,13 +114,8 @@ __device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTa
     const double r = c2 * rcp_nr<2>(K);
     double pw = 1.0, base = r;
     for (int e = wp >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }     // scalar loop
-    if (wp & 1) {
-        double y = __builtin_amdgcn_rsq(r);
-        y = y * fma(-0.5 * r, y * y, 1.5);
-        y = y * fma(-0.5 * r, y * y, 1.5);
-        pw = pw * ((r > 0.0) ? r * y : 0.0);
-    }
-    const double w = pw * (SMALL ? exp_small_tab(-0.5 * (c2 - K), tb.expt) : exp_clamped(-0.5 * (c2 - K), tb));
+    if (wp & 1) pw = pw * sqrt_nr(r);
+    const double w = pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
     return (c2 < K + 1400.0) ? w : 0.0;
 }
 
@@ -126,10 +129,10 @@ constexpr int hist_tile() {
 }
 // wide records: the next step's model record is NOT requested ahead where a second copy of the record does not fit the
 // register file beside the object (16 bands with per-model errors or the closed-form screen, 32 bands)
-template <class SRC, bool SCRB>
+template <class SRC>
 constexpr bool hist_prefetch() {
     if (SRC::NB <= 8) return SRC::NB + SRC::NVAL <= 18;              // 16 waves per block, 128 registers: all but 7 / 8 bands with per-model errors
-    return 2 * SRC::NB + 2 * SRC::RW + (SCRB ? 2 * SRC::NB : 0) <= 96;
+    return 2 * SRC::NB + 2 * SRC::RW <= 96;
 }
 
 // wave-wide maximum of a float without the LDS pipe: DPP within rows of 16 lanes, then the four row results through scalar
@@ -148,33 +151,21 @@ __device__ __forceinline__ float wave_maxf_dpp(float v) {
 
 template <int TW>
 struct HistState {
-    double S[TW];            // per lane: fp64 sum of the non-candidates (flushed from s)
-    double Sc[TW];           // per lane: exact weights of the drained candidates
-    double lo[TW], hi[TW];   // per lane: largest chi2 <= K, smallest chi2 > K among the drained candidates
-    float s[TW], tmax[TW];   // per lane: non-candidate sum since the last flush; largest log2 weight seen
-    float tthr[TW];          // wave-uniform: candidates have log2 w above this
+    double S[TW];            // per lane, EXACT: sum of the weights
+    double Sc[TW];           // per lane: sum of the settled pairs' weights (EXACT: the best weight seen)
+    double wmx[TW];          // per lane: largest exact weight among the settled pairs (ln-max = ln L(mode) + ln of it)
+    float tmax[TW];          // per lane: largest log2 weight seen (the classifier's fp32 estimate)
+    float tthr[TW];          // wave-uniform: pairs with log2 w at or below this are dropped
+    double wamb[TW];         // wave-uniform: a settled weight above this (0.98 wt_thresh x the best seen) that is not stacked at once waits in the ambiguous list
     int pend[TW];            // wave-uniform: entries waiting in the object's candidate buffer
     int namb[TW];            // wave-uniform: entries in the ambiguous list
     int tick, next;
 };
 
-// SCRB: chi2 screen of the free scale, A - inter^2 / shape; obx = x / var per band, A = sum x^2 / var
-template <class SRC>
-__device__ __forceinline__ double hist_screen_b(const typename SRC::OR& o, const typename SRC::MR& m, const double (&xiv)[SRC::NB], double A) {
-    double inter = 0.0, shape = 0.0;
-#pragma unroll
-    for (int b = 0; b < SRC::NB; ++b) {
-        inter = fma(m.y[b], xiv[b], inter);
-        shape = fma(m.y[b] * o.v[b], m.y[b], shape);
-    }
-    const double rc = rcp_nr<1>(shape);
-    return fma(-inter * rc, inter, A);
-}
-
 // OBJK: the band count behind the power of chi2 is the OBJECT's (its observed bands; one object per wave, so it is wave-uniform):
 // band sets padded up to 12 / 16 / 24 / 32 bands, and objects with unobserved bands against unmasked models in modes Ai / B, where a
 // masked band carries inverse variance 0 (k_prep_objects) and adds exactly nothing to chi2 in the mask-free arithmetic.
-template <class SRC, int TW, int NW, bool EXACT, bool SCRB, bool OBJK = (SRC::NB > 8)>
+template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8)>
 __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
                                                    double wt_thresh, int normalize, Cand* __restrict__ amb, int64_t cap,
                                                    double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs,
@@ -189,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     double lgq = src_.lp.lg_full;
     constexpr int NOBJ = NW * TW;
     constexpr int CAP = 128, DTHR = CAP - 64;                             // ring entries per object; drain from DTHR pending entries on
-    using tag_t = typename std::conditional<SCRB, int32_t, uint16_t>::type;   // label index (< 65536, checked by the launcher) or model number
+    using tag_t = uint16_t;                                               // label index (< 65536, checked by the launcher)
     static_assert(WP >= 1 && WP <= 30, "chi2^(1/2) ... chi2^15");
     __shared__ __attribute__((aligned(16))) double tileA[TD];
     __shared__ __attribute__((aligned(16))) double tileB[TD];
@@ -227,6 +218,12 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     // log2 of the screening weight: t = (K/2) log2(chi2) - (chi2 - K) log2(e) / 2 - (K/2) log2(K)
     float T0 = (float)(-0.5 * K * log2(K));
     const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh * 0.99) : -INFINITY;       // the fp32 screen keeps a 1 % margin
+    // the drop bar: log2 of the share of the best weight below which a pair cannot matter to an fp64 sum over M of them
+    // (2^-55 / M, and one more bit for the classifier's own error: |t - log2 w| < 1e-4 for every pair that could sit at the bar of an
+    // object that stays here, see `ok`); never above the stacking threshold
+    int mbits = 0;
+    while (((int64_t)1 << mbits) < (int64_t)M) ++mbits;
+    const float ldrop = fminf(lthr2, -(float)(56 + mbits));
     const double thr_def = wt_thresh * (1.0 + 1e-3);              // above this a weight is stacked whatever the maximum turns out to be
     auto lnl_c2 = [&](double c2) {
         if constexpr (KRT) return (wpr == 0) ? fma(-0.5, c2, -lgq) : chi2_logpdf<true>(0.5 * K, c2, lgq, tb);      // (power 0: no x log x term)
@@ -273,7 +270,6 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         // the wave's objects stay in VGPRs for the whole model loop (an LDS broadcast read: the compiler
         // cannot tell that they are wave-uniform and keeps them out of the scalar file)
         typename SRC::OR ob[TW];
-        double xiv[TW][BT], Aq[TW];
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
             src.load_obj_lds(objs + o * OD, ob[o]);
@@ -283,17 +279,14 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #pragma unroll
                 for (int b = 0; b < BT; ++b) ob[o].x[b] = uniform_d(ob[o].x[b]);
             }
-            if constexpr (SCRB) {
-                Aq[o] = 0.0;
-#pragma unroll
-                for (int b = 0; b < BT; ++b) { xiv[o][b] = ob[o].x[b] * ob[o].v[b]; Aq[o] = fma(xiv[o][b], ob[o].x[b], Aq[o]); }
-            }
         }
         HistState<TW> hs;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
-            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.lo[o] = -INFINITY; hs.hi[o] = INFINITY; hs.s[o] = 0.f; hs.tmax[o] = -200.f;
-            hs.tthr[o] = -120.f; hs.pend[o] = 0; hs.namb[o] = 0;
+            hs.S[o] = 0.0; hs.Sc[o] = 0.0; hs.wmx[o] = 0.0;
+            hs.tmax[o] = -INFINITY;
+            hs.tthr[o] = -INFINITY;                          // (nothing is dropped before the first look at the best weight, after step 1)
+            hs.wamb[o] = 0.0; hs.pend[o] = 0; hs.namb[o] = 0;
         }
         hs.tick = 0; hs.next = 1;
 
@@ -302,12 +295,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         auto settle = [&](int o, bool act, double c2, int tag) {
             const double w = act ? exactw_tab(c2, tbx, std::integral_constant<bool, !EXACT>{}) : 0.0;
             hs.Sc[o] += w;
-
-            const bool below = c2 <= K;
-            hs.lo[o] = vmax_raw(hs.lo[o], (act && below) ? c2 : -INFINITY);
-            hs.hi[o] = vmin_raw(hs.hi[o], (act && !below) ? c2 : INFINITY);
+            hs.wmx[o] = vmax_raw(hs.wmx[o], w);
             if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + tag + w0], w);
-            const bool am = act && !(w > thr_def);
+            // (every pair that can matter to the evidence comes through here, not only the few near the threshold: the ambiguous list
+            //  takes those within wt_thresh of the best weight seen so far -- a superset of what the exact maximum will admit)
+            const bool am = act && !(w > thr_def) && w > hs.wamb[o];
             const unsigned long long mask = __ballot(am);
             if (mask) {                                           // wave-uniform
                 const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
@@ -320,26 +312,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 } else hs.namb[o] = -1;                           // overflowed: nothing more is stored, the object goes to the sweep
             }
         };
-        // settle the first (up to) 64 entries of object o's buffer with all lanes; what lies behind them moves to the front
+        // settle the LAST (up to) 64 entries of object o's buffer with all lanes (their order does not matter: nothing has to move)
         auto drain = [&](int o) {
             const int n = hs.pend[o] < 64 ? hs.pend[o] : 64;
-            double c2 = rc2[o * CAP + lane];
-            int tag = (int)rtag[o * CAP + lane];
             const int rest = hs.pend[o] - n;                      // < 64
-            if (rest > 0) {                                       // wave-uniform
-                const double c2b = rc2[o * CAP + 64 + lane];
-                const tag_t tgb = rtag[o * CAP + 64 + lane];
-                if (lane < rest) { rc2[o * CAP + lane] = c2b; rtag[o * CAP + lane] = tgb; }
-            }
+            double c2 = rc2[o * CAP + rest + lane];
+            int tag = (int)rtag[o * CAP + rest + lane];
             const bool act = lane < n;
-            if constexpr (SCRB) {
-                // the buffer holds the model number: exact residual-form chi2 from the record (pdf.py:181-189)
-                const int j = act ? tag : 0;
-                typename SRC::MR m;
-                src.load_model_rec16(j, m);
-                tag = posw[j];
-                c2 = src.chi2_of(ob[o], m);
-            }
             settle(o, act, c2, tag);
             hs.pend[o] = rest;
         };
@@ -353,14 +332,14 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 // branch, follow), and the next trip's records are requested before the current ones are used
                 constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
                 static_assert((TILE / 64) % MP == 0, "groups per trip must divide the tile");
-                constexpr bool PF = hist_prefetch<SRC, SCRB>();
+                constexpr bool PF = hist_prefetch<SRC>();
                 typename SRC::MR mn[PF ? MP : 1];
                 int tagn[MP];
                 if constexpr (PF) {
 #pragma unroll
                     for (int q = 0; q < MP; ++q) {
                         src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
-                        tagn[q] = SCRB ? 0 : tags[q * 64 + lane];
+                        tagn[q] = tags[q * 64 + lane];
                     }
                 }
 #pragma unroll
@@ -370,14 +349,14 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #pragma unroll
                     for (int q = 0; q < MP; ++q) {
                         if constexpr (PF) { m[q] = mn[q]; ptag[q] = tagn[q]; }
-                        else { src.template load_model_lds<TILE>(cur, (st + q) * 64 + lane, m[q]); ptag[q] = SCRB ? 0 : tags[(st + q) * 64 + lane]; }
+                        else { src.template load_model_lds<TILE>(cur, (st + q) * 64 + lane, m[q]); ptag[q] = tags[(st + q) * 64 + lane]; }
                         asm volatile("" : "+v"(ptag[q]));         // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
                     }
                     if (PF && st + MP < TILE / 64) {
 #pragma unroll
                         for (int q = 0; q < MP; ++q) {
                             src.template load_model_lds<TILE>(cur, (st + MP + q) * 64 + lane, mn[q]);
-                            if (!SCRB) tagn[q] = tags[(st + MP + q) * 64 + lane];
+                            tagn[q] = tags[(st + MP + q) * 64 + lane];
                         }
                     }
                     double c2[MP][TW];
@@ -385,7 +364,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     for (int q = 0; q < MP; ++q)
 #pragma unroll
                         for (int o = 0; o < TW; ++o) {
-                            c2[q][o] = SCRB ? hist_screen_b<SRC>(ob[o], m[q], xiv[o], Aq[o]) : src.chi2_of(ob[o], m[q]);
+                            c2[q][o] = src.chi2_of(ob[o], m[q]);
                             if (TAIL) c2[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? c2[q][o] : 1e30;   // pad lanes: weight 0
                         }
                     if constexpr (EXACT) {
@@ -414,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             for (int o = 0; o < TW; ++o) hs.Sc[o] = wave_max(hs.Sc[o]);
                         }
                     } else {
-                        float tl[MP][TW], w[MP][TW];
+                        float tl[MP][TW];
 #pragma unroll
                         for (int q = 0; q < MP; ++q)
 #pragma unroll
@@ -423,27 +402,23 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                 const float l2 = __builtin_amdgcn_logf(cf);             // chi2 == 0: -inf; a negative screen value: nan
                                 const float df = (float)(c2[q][o] - K);                 // fp64 difference, then fp32
                                 tl[q][o] = fmaf(l2, halfk, fmaf(df, -0.72134752f, T0));   // -inf for chi2 == 0; nan only beyond fp32's range
+                                if (TAIL) tl[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? tl[q][o] : -INFINITY;   // pad lanes: dropped whatever the bar
                             }
-#pragma unroll
-                        for (int q = 0; q < MP; ++q)
-#pragma unroll
-                            for (int o = 0; o < TW; ++o) w[q][o] = __builtin_amdgcn_exp2f(tl[q][o]);
 #pragma unroll
                         for (int q = 0; q < MP; ++q) {
 #pragma unroll
                             for (int o = 0; o < TW; ++o) {
-                                // ONE compare: at or below the bar -> the fp32 remainder; above it (or not a number: chi2 beyond fp32's
-                                // range, settled like any candidate and found weightless) -> the candidate buffer
+                                // ONE compare: at or below the bar -> dropped (it cannot matter to an fp64 sum);
+                                // above it (or not a number: chi2 beyond fp32's range, settled like any other and found weightless) -> the buffer
                                 const bool le = tl[q][o] <= hs.tthr[o];
                                 const bool c = !le;
                                 asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[q][o]));   // (a nan operand yields the other one)
-                                hs.s[o] += le ? w[q][o] : 0.f;
-                                // candidates -> the object's buffer (ballot + mbcnt compaction); its fill level is a wave-uniform scalar
+                                // -> the object's buffer (ballot + mbcnt compaction); its fill level is a wave-uniform scalar
                                 const unsigned long long mask = __ballot(c);
                                 // (v_mbcnt adds its count to a base: the fill level)  < 64 wait when a group begins, a group adds at most 64: never past CAP
                                 const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, hs.pend[o]));
 #if !defined(FZ_DIAG_NOAPPEND)
-                                if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)(SCRB ? t * TILE + (st + q) * 64 + lane : ptag[q]); }
+                                if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)ptag[q]; }
 #endif
                                 hs.pend[o] += __builtin_popcountll(mask);
                             }
@@ -451,10 +426,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                 hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
 #pragma unroll
                                 for (int o = 0; o < TW; ++o) {
-                                    hs.S[o] += (double)hs.s[o]; hs.s[o] = 0.f;          // fp32 partial sums -> fp64
-                                    const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bar follows the wave-wide best weight seen
+                                    const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
                                     hs.tmax[o] = mx;
-                                    hs.tthr[o] = fmaxf(mx + lthr2, -120.f);
+                                    hs.tthr[o] = mx + ldrop;
+                                    // 0.98 wt_thresh 2^mx in fp64 (mx may lie below fp32's exponent range): 2^frac by v_exp_f32, 2^int by v_ldexp_f64
+                                    const float fl = floorf(mx);
+                                    const double wb = (mx > -1000.f) ? __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(mx - fl), (int)fl) : 0.0;
+                                    hs.wamb[o] = uniform_d(wb * (wt_thresh * 0.98));
                                 }
                             }
 #pragma unroll
@@ -493,22 +471,16 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 } else {
                     wbest_run = wave_max(hs.Sc[o]);
                 }
-                double lbest;                                                  // exact ln-like of the best model
-                if constexpr (EXACT) {
-                    // ln L of the best model = ln L(mode) + ln of its exact relative weight (4e-16 relative on the weight: 1e-16 on ln-max)
-                    lbest = (wbest_run > 0.0) ? uniform_d(lref + log_pos(wbest_run, tb)) : -INFINITY;
-                } else {
-                    const double l = wave_max(hs.lo[o]), h = -wave_max(-hs.hi[o]);
-                    const double ll = (l >= 0.0) ? lnl_c2(l) : -INFINITY;
-                    const double lh = (h < 1e299) ? lnl_c2(h) : -INFINITY;
-                    lbest = uniform_d(fmax(ll, lh));
-                }
-                const double stot = EXACT ? wave_sum(hs.S[o]) : wave_sum(hs.Sc[o]) + wave_sum(hs.S[o] + (double)hs.s[o]);
+                // ln L of the best model = ln L(mode) + ln of its exact relative weight (4e-16 relative on the weight: 1e-16 on ln-max)
+                if constexpr (!EXACT) wbest_run = wave_max(hs.wmx[o]);
+                const double lbest = (wbest_run > 0.0) ? uniform_d(lref + log_pos(wbest_run, tb)) : -INFINITY;
+                const double stot = wave_sum(EXACT ? hs.S[o] : hs.Sc[o]);
                 const double le = lref + log_pos(stot, tb);
                 const float tm = EXACT ? 0.f : wave_maxf(hs.tmax[o]);
-                // no candidate at all, an evidence that is not a number, or a best weight so far below the mode
-                // that the fp32 remainder has lost terms (2^-126 / 2^-80: still 2^-46 below the best): the exact ln-space sweep decides
-                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -80.f)) && hs.namb[o] >= 0 && kok;
+                // no candidate at all, an evidence that is not a number, or a best weight so far below the mode that weights relative to
+                // the MODE leave the comfortable range (2^-400: every pair within the drop bar of it is still a normal number well above
+                // the exponential's clamp, and chi2 stays small enough -- < ~600 -- for the classifier's error bound): the exact ln-space sweep decides
+                const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -400.f)) && hs.namb[o] >= 0 && kok;
                 // the ambiguous band, by the reference's own rule (pdf.py:591) with the exact maximum and evidence
                 const int na = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                 if (na > 0) {

@@ -146,6 +146,8 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.errhi = st.err + n; st.firstnan = c->d_mcfn.as<int>();
     st.lnl_only = 0; st.lgtab = c->d_lgB.as<double>();
+    FZCHK(c->d_mcniter.ensure(n * 4)); st.niter = c->d_mcniter.as<int>(); c->mc_niter_n = n;
+    HIPCHK(hipMemsetAsync(st.niter, 0, n * 4, c->stream));
     // Active-object lists and their lengths live on the device and alternate between two slots; the host
     // queues FZ_MODEC_BURST iterations (step + stop rule, launched for the object count it last saw: blocks
     // of objects that stopped since exit at once) before it looks at the count again, so the loop is not
@@ -184,23 +186,27 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
         auto run = [&](auto fastc, const int* list, int64_t nobj) -> int {
             constexpr bool F = decltype(fastc)::value;
             using MCT = ModeC<BT, MASKED>;
-            if (M <= 1024) return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, list, nobj);
-            if (M <= 4096) return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, list, nobj);
-            if (M <= 768 * 14) return launch(k_modec_persist<MCT, F, 768, 14>, 768, list, nobj);
+            if (M <= 1024) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, list, nobj); }
+            if (M <= 4096) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, list, nobj); }
+            if (M <= 768 * 14) { c->mc_info[3] = 768; return launch(k_modec_persist<MCT, F, 768, 14>, 768, list, nobj); }
+            c->mc_info[3] = 512;
             return launch(k_modec_persist<MCT, F, 512, 32>, 512, list, nobj);
         };
         if (fast) FZCHK(run(std::true_type{}, nullptr, n)); else FZCHK(run(std::false_type{}, nullptr, n));
         int res[3] = {0, 0, 0};                              // status, slowest object's iterations, ambiguous objects
         HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (fast && res[2] > 0 && !res[0]) {
-            FZCHK(run(std::false_type{}, st.amb, res[2]));
+        const int namb = res[2];
+        if (fast && namb > 0 && !res[0]) {
+            FZCHK(run(std::false_type{}, st.amb, namb));
             HIPCHK(hipMemcpyAsync(res, counts + 1, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            res[2] = namb;
         }
         HIPCHK(hipGetLastError());
         if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
                                     "(the reference loop at pdf.py:199 would not terminate)", max_iter);
+        c->mc_info[0] += fast ? res[2] : 0; c->mc_info[1] = std::max<int64_t>(c->mc_info[1], res[1]); c->mc_info[2] = 1;
         c->tm.n_modec += res[1];         // iterations of the slowest object (the two timed scopes add the other two counts the bench subtracts)
         return 0;
     }
@@ -251,6 +257,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     HIPCHK(hipMemcpyAsync(&it_max, counts + 2, 4, hipMemcpyDeviceToHost, c->stream));      // iterations the slowest object took, minus one
     HIPCHK(hipStreamSynchronize(c->stream));
     ++it_max;
+    c->mc_info[0] += namb; c->mc_info[1] = std::max<int64_t>(c->mc_info[1], it_max); c->mc_info[2] = 2; c->mc_info[3] = 0;
     c->tm.n_modec += it_max;         // iterations of the slowest object of the chunk (+1 per timed scope: the initial pass)
     HIPCHK(hipGetLastError());
     return 0;

@@ -138,11 +138,31 @@ __host__ __device__ inline unsigned knn_prefix12(const double* v, const float* b
     for (int n = 0; n < nb; ++n) p = (p << 1) | ((qv[n % F] >> (9 - n / F)) & 1u);
     return p << (12 - nb);
 }
+// leaf (= 64-model tile) of a point in a set's implicit k-d tree (k-d order of the models, fz_knn_host.inc): the node over tiles [a, b)
+// splits at mid = a + (b - a) / 2 along feature sp[2 mid] at value sp[2 mid + 1] (float bits)
+__device__ inline int knn_kd_leaf(const double* v, const int* __restrict__ sp, int ntiles) {
+    int a = 0, b = ntiles;
+    while (b - a > 1) {
+        const int mid = a + (b - a) / 2;
+        const int d = sp[2 * mid];
+        const float sv = __int_as_float(sp[2 * mid + 1]);
+        if ((float)v[d] < sv) b = mid; else a = mid;
+    }
+    return a;
+}
+// bucket of a query for the counting sort: its leaf in set 0's k-d tree (scaled into 4096 buckets), or its 12-bit Morton prefix
+__device__ inline unsigned knn_qbucket(const double* v, const float* bnd, int F, const int* __restrict__ sp, int kdn) {
+    if (kdn <= 0) return knn_prefix12(v, bnd, F);
+    int sh = 0;
+    while ((kdn >> sh) > 4096) ++sh;
+    return (unsigned)(knn_kd_leaf(v, sp, kdn) >> sh);
+}
 // counting sort of the queries by prefix (the order inside a bucket is whatever the atomics give: every query's
 // result is independent of the wave that computes it)
-static __global__ void k_knn_qhist(const double* __restrict__ q, int64_t N, int F, const float* __restrict__ bnd, int* __restrict__ cnt) {
+static __global__ void k_knn_qhist(const double* __restrict__ q, int64_t N, int F, const float* __restrict__ bnd, int* __restrict__ cnt,
+                                   const int* __restrict__ sp, int kdn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) atomicAdd(&cnt[knn_prefix12(q + i * F, bnd, F)], 1);
+    if (i < N) atomicAdd(&cnt[knn_qbucket(q + i * F, bnd, F, sp, kdn)], 1);
 }
 static __global__ __launch_bounds__(1024) void k_knn_qscan(int* __restrict__ cnt) {       // exclusive scan of 4096 counts, one block
     __shared__ int part[1024];
@@ -156,9 +176,9 @@ static __global__ __launch_bounds__(1024) void k_knn_qscan(int* __restrict__ cnt
     for (int u = 0; u < 4; ++u) { cnt[4 * t + u] = base; base += v[u]; }
 }
 static __global__ void k_knn_qscatter(const double* __restrict__ q, int64_t N, int F, const float* __restrict__ bnd, int* __restrict__ off,
-                                      int* __restrict__ qperm) {
+                                      int* __restrict__ qperm, const int* __restrict__ sp, int kdn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) qperm[atomicAdd(&off[knn_prefix12(q + i * F, bnd, F)], 1)] = (int)i;
+    if (i < N) qperm[atomicAdd(&off[knn_qbucket(q + i * F, bnd, F, sp, kdn)], 1)] = (int)i;
 }
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -262,7 +282,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                                                          const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
-                                                         const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd) {
+                                                         const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd, int kdorder) {
     static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
     static_assert(KPL == 0 || KPL == 5 || KPL == 8, "register lists: k <= 20 or k <= 32");
     constexpr int TF = FZ_KM_TSTR;
@@ -438,7 +458,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         double qm[8];
 #pragma unroll
         for (int f = 0; f < 6; ++f) qm[f] = qs[wave][8][f];
-        const int hm = ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
+        // k-d order: the leaf of the wave's middle query in THIS set's tree (11 dependent pairs of scalar loads at M = 1e5); Morton order: the prefix table
+        const int hm = kdorder ? knn_kd_leaf(&qs[wave][8][0], ktab + (size_t)tree * ntiles * 2, ntiles) :     // (the query straight from LDS: a dynamic index into registers would go to scratch)
+                                 ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
         sc.nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); sc.nl = sc.nr - 1;
     }
     sc.fetch(bm, sl);

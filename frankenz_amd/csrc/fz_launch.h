@@ -395,11 +395,11 @@ int fz_launch_nolist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
 // exact: every weight in fp64 (the all-fp64 evidence, and the form for broad likelihoods)
 // OBJK / SWS: per-object band counts (fz_hist.h); the sweep over handed-back objects then runs on `sws`, the MASKED variant of
 // the same likelihood when objects may have unobserved bands (the mask-free arithmetic of `src` does not know N_dim per object)
-template <class SRC, int TW, int NW, bool EXACT, bool SCRB, bool OBJK = (SRC::NB > 8), class SWS = SRC>
+template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), class SWS = SRC>
 int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                      double* lmap, double* levid, double* pdfs, const SWS* swsp = nullptr) {
     constexpr int SW = 4;
-    auto kern = fz::k_hist<SRC, TW, NW, EXACT, SCRB, OBJK>;
+    auto kern = fz::k_hist<SRC, TW, NW, EXACT, OBJK>;
     const size_t lds = (size_t)NW * TW * kv.acc_stride * 8;
     {
         hipFuncAttributes fa;
@@ -472,31 +472,17 @@ int fz_launch_hist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, 
     if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 30) || (SRC::NB > 16 && SRC::LMODE == 0)) return 1;
     else {
         if (!src.lp.dim_prior || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31)) return 1;
-        constexpr bool SB = (SRC::LMODE == 2);
-        const bool scrb = SB && !getenv("FZ_HIST_NOSCRB");
+        // the free scale (mode B) weighs every pair in fp64 straight away: its chi2 takes two passes over the bands, and screening with
+        // the closed form first was slower (fz_hist.h)
+        const bool ex = exact || SRC::LMODE == 2;
         if constexpr (SRC::NB > 8) {
             // wide records: one object per wave, eight waves per block (up to 256 registers per lane)
-            if (getenv("FZ_HIST_WIDE") && atoi(getenv("FZ_HIST_WIDE")) == 0) return 1;
-            if (exact) return fz_launch_hist_g<SRC, 1, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            if constexpr (SB) {
-                if (scrb) return fz_launch_hist_g<SRC, 1, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            }
-            return fz_launch_hist_g<SRC, 1, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            if (ex) return fz_launch_hist_g<SRC, 1, 8, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            return fz_launch_hist_g<SRC, 1, 8, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
-            int tw = 1, nw = 16;
-            if (const char* e = getenv("FZ_HIST_CFG")) sscanf(e, "%d,%d", &tw, &nw);
-            if (exact) {
-                if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                return fz_launch_hist_g<SRC, 2, 8, true, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            }
-            if constexpr (SB) {
-                if (scrb) {
-                    if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                    return fz_launch_hist_g<SRC, 2, 8, false, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                }
-            }
-            if (tw == 1) return fz_launch_hist_g<SRC, 1, 16, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-            return fz_launch_hist_g<SRC, 2, 8, false, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            if (ex) return fz_launch_hist_g<SRC, 1, 16, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            if constexpr (SRC::LMODE != 2) return fz_launch_hist_g<SRC, 1, 16, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
+            return 1;
         }
     }
 }
@@ -511,16 +497,15 @@ int fz_launch_hist_objmask(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n,
         fz::KdeView kv;
         FZCHK(fz_kde_view(c, kv));
         if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_OBJMASK") && atoi(getenv("FZ_HIST_OBJMASK")) == 0)) return 1;
-        const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
-        if (exact || !(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
+        // (every form of k_hist forms and sums its weights in fp64: a request for the exact evidence needs no other kernel)
+        if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
         if (!src.lp.dim_prior && getenv("FZ_HIST_NODIMPRIOR") && atoi(getenv("FZ_HIST_NODIMPRIOR")) == 0) return 1;
         fz_exact_now() = false;
-        constexpr bool SB = (SRC::LMODE == 2);
         constexpr int NWH = SRC::NB > 8 ? 8 : 16;
         int r;
-        if (SB && !getenv("FZ_HIST_NOSCRB")) r = fz_launch_hist_g<SRC, 1, NWH, false, SB, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
-        else r = fz_launch_hist_g<SRC, 1, NWH, false, false, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
-        if (r <= 0) c->last_form = "k_hist<screen> (per-object band counts)";
+        if constexpr (SRC::LMODE == 2) r = fz_launch_hist_g<SRC, 1, NWH, true, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
+        else r = fz_launch_hist_g<SRC, 1, NWH, false, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
+        if (r <= 0) c->last_form = SRC::LMODE == 2 ? "k_hist<exact> (per-object band counts)" : "k_hist<screen> (per-object band counts)";
         return r;
     }
 }
@@ -531,10 +516,11 @@ int fz_launch_hist_only(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const f
     fz::KdeView kv;
     FZCHK(fz_kde_view(c, kv));
     if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0)) return 1;
-    const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
-    fz_exact_now() = exact;
+    // FZ_EXACT_EVIDENCE=1 (tests): the form that weighs every pair without classifying it first
+    const bool exact = getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0;
+    fz_exact_now() = exact || c->exact_evidence;
     const int r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact);
-    if (r <= 0) c->last_form = exact ? "k_hist<exact>" : "k_hist<screen>";
+    if (r <= 0) c->last_form = (exact || SRC::LMODE == 2) ? "k_hist<exact>" : "k_hist<screen>";
     return r;
 }
 
@@ -585,24 +571,26 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // (objects per wave, waves per block).  Few objects: one per wave so that the
         // chunk spreads over the chip.  FZ_FUSED_CFG=tw,nw overrides (tuning aid).
         int r = 1;
-        // the default where it applies: one pass, LDS histograms, no candidate lists (fz_hist.h); FZ_HIST=0 keeps k_fused,
-        // FZ_EXACT_EVIDENCE=1 (or like_opts.exact_evidence) the all-fp64 form
-        const bool exact = c->exact_evidence || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
-        fz_exact_now() = exact;
+        // the default where it applies: one pass, LDS histograms, no candidate lists, every weight and sum in fp64 (fz_hist.h); FZ_HIST=0
+        // keeps k_fused, FZ_EXACT_EVIDENCE=1 (tests) the form that weighs every pair without classifying it first.  like_opts.exact_evidence
+        // matters to k_fused's weight-space body only (fp32 remainder of the evidence there)
+        const bool exact = getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0;
+        fz_exact_now() = exact || c->exact_evidence;
         double share = -2.0;                                     // not sampled yet
         if (!getenv("FZ_HIST") || atoi(getenv("FZ_HIST")) != 0) {
-            // When most pairs are within the weight threshold (faint data: the reference's own mock sits at 41 %), screening
-            // them first is wasted work: the all-fp64 form, which weighs every pair directly, is the faster one from ~45 % on
-            // (bench.py --noise-scale 3 / 10: 53 % / 95 %).  FZ_NOLIST=1 / 0 forces / forbids the switch.
+            // The classifier pays when it drops most pairs: with 7 % of the pairs within wt_thresh of the best (41 % above the drop
+            // bar) it runs level with the form that weighs every pair directly (53.4 vs 54.9 ms per 2.6e10 pairs), with 3 % ahead of
+            // it (46.0 vs 55.2); for broader likelihoods (faint data: the reference's own mock sits at 41 %; bench.py --noise-scale
+            // 3 / 10: 53 % / 95 %) the direct form is the faster one.  FZ_NOLIST=1 / 0 forces / forbids the switch.
             bool broad = false;
             if (!exact) {
                 const char* e = getenv("FZ_NOLIST");
                 const int want = e ? atoi(e) : -1;
-                if (want < 0 && n >= 16384) { share = fz_nolist_probe<SRC>(c, src, kv, n, M, ko); broad = share > 0.45; }
+                if (want < 0 && n >= 16384) { share = fz_nolist_probe<SRC>(c, src, kv, n, M, ko); broad = share > 0.12; }
                 else broad = want == 1;
             }
             r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact || broad);
-            if (r <= 0) { c->last_form = (exact || broad) ? (exact ? "k_hist<exact>" : "k_hist<exact> (broad likelihoods)") : "k_hist<screen>"; return r; }
+            if (r <= 0) { c->last_form = (exact || broad || SRC::LMODE == 2) ? ((exact || SRC::LMODE == 2) ? "k_hist<exact>" : "k_hist<exact> (broad likelihoods)") : "k_hist<screen>"; return r; }
         }
         // broad likelihoods run without candidate lists (fz_nolist.h: two passes over the models, nothing in HBM).  The
         // share of pairs within the weight threshold is measured on 256 sampled objects of the launch; FZ_NOLIST=1 / 0

@@ -46,6 +46,7 @@ struct ModeCState {
     // and s / c / sh are not written at all (three 8 B-per-pair planes and the k_modec_final pass less)
     int lnl_only;
     const double* lgtab;
+    int* niter;                // (Nc) iterations each object took (the count of pdf.py:199's loop passes); may be nullptr
 };
 
 // Optional indirection for the k-NN subset (knn.py:847-849): object i's "model" slot j is
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
                 else { st.s[k] = sn; st.l[k] = ln; st.c[k] = c; st.sh[k] = sh; }
             }
         }
-        if (tid == 0) atomicMax(st.last_iter, iters);
+        if (tid == 0) { atomicMax(st.last_iter, iters); if (st.niter) st.niter[i] = iters; }
         __syncthreads();
     }
 }
@@ -299,6 +300,7 @@ static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol, int
     const double e = __longlong_as_double((long long)st.err[i]);
     const bool go = !st.firstnan[i] && (e > ltol);       // `while lerr > ltol`
     st.err[i] = 0ull;
+    if (st.niter) st.niter[i] = iter;                    // the last check an object sees is the one that stops it
     // FAST solve: ltol between the two bounds of the object's error -- the IEEE iterates could decide the other way
     if (st.amb) {
         const double ehi = __longlong_as_double((long long)st.errhi[i]);

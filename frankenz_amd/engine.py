@@ -98,6 +98,54 @@ def _digest(*arrays):
     return (tuple(a.shape for a in arrays), h.hexdigest())
 
 
+class _PinnedBlock(object):
+    """A page-locked host block (fz_host_alloc) behind ``__array_interface__``: the NumPy array made from it keeps it alive
+    as its base; when the last view dies the block goes back to a small pool (page-locking 5.6 GB costs about as much
+    as copying it) or to the runtime."""
+    _pool = []                      # free blocks [(nbytes, ptr)], at most _POOL_MAX bytes in total
+    _POOL_MAX = 12 << 30
+
+    def __init__(self, ptr_, nbytes, shape, dtype):
+        self.ptr, self.nbytes = ptr_, nbytes
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str, "data": (ptr_, False), "version": 3}
+
+    def __del__(self):
+        try:
+            pool = _PinnedBlock._pool
+            if sum(b[0] for b in pool) + self.nbytes <= _PinnedBlock._POOL_MAX:
+                pool.append((self.nbytes, self.ptr))
+            else:
+                _lib.load().fz_host_free(self.ptr)
+        except Exception:           # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64, min_bytes=1 << 24):
+    """Uninitialised result array in page-locked host memory (arrays below ``min_bytes`` and any allocation the runtime
+    refuses: ordinary ``np.empty``).  A device-to-host copy into pageable memory is staged by the runtime (~14 GB/s
+    measured, and it blocks the host); into page-locked memory it runs at the link rate behind the next chunk's kernel."""
+    shape = tuple(int(v) for v in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(v) for v in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes < min_bytes:
+        return np.empty(shape, dtype=dtype)
+    pool = _PinnedBlock._pool
+    best = None
+    for k, (nb, _) in enumerate(pool):          # smallest free block that fits without wasting more than half of itself
+        if nbytes <= nb <= 2 * nbytes and (best is None or nb < pool[best][0]):
+            best = k
+    if best is not None:
+        nb, p = pool.pop(best)
+    else:
+        h = C.c_void_p()
+        if _lib.load().fz_host_alloc(nbytes, C.byref(h)) != 0:
+            while pool:                         # make room once, then give up on page-locking
+                _lib.load().fz_host_free(pool.pop()[1])
+            if _lib.load().fz_host_alloc(nbytes, C.byref(h)) != 0:
+                return np.empty(shape, dtype=dtype)
+        nb, p = nbytes, h.value
+    return np.asarray(_PinnedBlock(p, nb, shape, dtype))
+
+
 class Engine(object):
     """One device context.  Not thread-safe."""
 
@@ -169,7 +217,7 @@ class Engine(object):
         key = ("grid", float(dx), float(sig_thresh), self._models_key) + _digest(y, ys, g)
         if key == self._labels_key:
             return
-        self._labels_key = None
+        self._labels_key = None              # (the library restores the dictionary's grid length itself when dictionary labels return)
         check(self.lib.fz_labels_upload_grid(self.h, ptr(y), ptr(ys), len(y), ptr(g), len(g),
                                              float(dx), float(sig_thresh)))
         self._labels_key = key
@@ -290,6 +338,37 @@ class Engine(object):
         check(self.lib.fz_overlap_nz(self.h, ptr(pdfs), n, len(nz), ptr(nz), pi, pj, float(step), ptr(overlap), ptr(out)))
         return float(out[0])
 
+    def knn_search_fit_predict(self, q, x, xe, xm, k, lp_norm, distance_upper_bound, opts, kopts, prior=None,
+                               neighbors=None, nnbr=None, lnprior=None, lnlike=None, lnprob=None, chi2=None, ndim=None,
+                               scale=None, scale_err=None, pdfs=None, lmap=None, levid=None, n=None):
+        """fz_knn_search_fit_predict_prior: the K searches and the subset likelihood / PDFs in one call, the neighbour
+        table staying on the device"""
+        n = len(x) if n is None else n
+        check(self.lib.fz_knn_search_fit_predict_prior(
+            self.h, ptr(q), ptr(x), ptr(xe), ptr(xm), n, int(k), float(lp_norm), float(distance_upper_bound),
+            C.byref(opts), C.byref(kopts) if kopts is not None else None, self._prior_struct(prior), ptr(neighbors),
+            ptr(nnbr), ptr(lnprior), ptr(lnlike), ptr(lnprob), ptr(chi2), ptr(ndim), ptr(scale), ptr(scale_err),
+            ptr(pdfs), ptr(lmap), ptr(levid)))
+
+    def set_producer_stream(self, stream=None, mode=1):
+        """fz_set_producer_stream.  ``mode`` 0: device-wide wait before device inputs are read (default of a fresh
+        engine); 1: wait for ``stream`` only (an int ``hipStream_t``, e.g. ``torch.cuda.current_stream().cuda_stream``;
+        None / 0: the legacy default stream); 2: inputs are complete, no wait."""
+        check(self.lib.fz_set_producer_stream(self.h, int(stream or 0), int(mode)))
+
+    def modec_info(self):
+        """mode C since the last ``timing_reset``: ``(ambiguous objects re-run with IEEE divisions, iterations of the
+        slowest object, 1 = one block per object / 2 = state planes, threads per block)``"""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.lib.fz_modec_info(self.h, ptr(out)))
+        return tuple(int(v) for v in out)
+
+    def modec_niter(self, n):
+        """passes of the loop at pdf.py:199 each of the first ``n`` objects of the last mode-C chunk took"""
+        out = np.zeros(int(n), dtype=np.int32)
+        check(self.lib.fz_modec_niter(self.h, int(n), ptr(out)))
+        return out
+
     def clean(self, x, xe, xm):
         check(self.lib.fz_clean(self.h, ptr(x), ptr(xe), ptr(xm), x.shape[0], x.shape[1]))
 
@@ -297,6 +376,7 @@ class Engine(object):
         check(self.lib.fz_sync(self.h))
 
     def timing_reset(self):
+        """zero the per-family timers (and the mode-C bookkeeping of ``modec_info``)"""
         check(self.lib.fz_timing_reset(self.h))
 
     def timing(self):

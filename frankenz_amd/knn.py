@@ -19,7 +19,7 @@ import numpy as np
 
 from . import pdf as _pdf
 from .bruteforce import _check_lprob, _progress
-from .engine import HostObjects, _digest, get_engine, kde_opts, like_opts, merge_kde_args
+from .engine import HostObjects, _digest, get_engine, kde_opts, like_opts, merge_kde_args, pinned_empty
 
 __all__ = ["NearestNeighbors"]
 
@@ -34,6 +34,73 @@ class _FeatureSet(object):
         self.data = data
         self.n, self.m = data.shape
         self.leafsize = leafsize
+
+
+class _PreparedKnn(object):
+    """Model set + feature sets + labels resident on the device and the options of one ``fit_predict(save_fits=False)``
+    configuration (``NearestNeighbors.prepare_fit_predict``)."""
+
+    def __init__(self, nn, eng, opts, ko, Nx, prior, labels):
+        self.nn, self.eng, self.opts, self.ko, self.Nx, self.prior, self._labels = nn, eng, opts, ko, Nx, prior, labels
+        self.search = (nn.k, nn.lp_norm, nn.dbound)
+        self._keys = (eng._models_key, eng._dict_key, eng._labels_key, eng._trees_key)
+
+    def _ensure_resident(self):
+        eng = self.eng
+        if (eng._models_key, eng._dict_key, eng._labels_key, eng._trees_key) == self._keys:
+            return
+        self.nn._engine()                           # models + feature sets (content keys: free when unchanged)
+        eng.set_labels(*self._labels)
+        self._keys = (eng._models_key, eng._dict_key, eng._labels_key, eng._trees_key)
+
+    def run(self, data, data_err, data_mask, out=None, query_features=None, rstate=None):
+        """-> (pdfs, lmap, levid).  ``data*``: NumPy arrays or contiguous float64 tensors on the engine's GPU (cleaned in place
+        by the library, pdf.py:310-311); ``query_features``: (Ndata, Nfilt) float64, NumPy or device tensor -- when None they are
+        drawn here from ``rstate`` exactly as knn.py:830-832 does (on the host: the stream is NumPy's), which needs the objects
+        on the host (device tensors are copied back for that one step)."""
+        nn, eng, Nx = self.nn, self.eng, self.Nx
+        self._ensure_resident()
+        on_dev = hasattr(data, "data_ptr")
+        Ndata = int(data.shape[0])
+        if query_features is None:
+            hx, hxe = (data.cpu().numpy(), data_err.cpu().numpy()) if on_dev else (np.asarray(data), np.asarray(data_err))
+            query_features = nn._query_features(hx, hxe, rstate if rstate is not None else np.random)
+        q = query_features
+        if not hasattr(q, "data_ptr"):
+            q = np.ascontiguousarray(q, dtype=np.float64)
+        if tuple(q.shape) != (Ndata, nn.NDIM):
+            raise ValueError("`query_features` must have shape (Ndata, Nfilt) = (%d, %d)" % (Ndata, nn.NDIM))
+        if out is None:
+            if on_dev:
+                import torch
+                out = (torch.empty((Ndata, Nx), dtype=torch.float64, device=data.device),
+                       torch.empty(Ndata, dtype=torch.float64, device=data.device),
+                       torch.empty(Ndata, dtype=torch.float64, device=data.device))
+            else:
+                out = (pinned_empty((Ndata, Nx)), np.zeros(Ndata), np.zeros(Ndata))
+        pdfs, lmap, levid = out
+        for a, shp in ((pdfs, (Ndata, Nx)), (lmap, (Ndata,)), (levid, (Ndata,))):
+            if tuple(a.shape) != shp or str(a.dtype).split('.')[-1] != 'float64':
+                raise ValueError("`out` must hold float64 arrays of shape (Ndata, Nx), (Ndata,), (Ndata,); got %s %s"
+                                 % (tuple(a.shape), a.dtype))
+            if (hasattr(a, "is_contiguous") and not a.is_contiguous()) or (isinstance(a, np.ndarray) and not a.flags.c_contiguous):
+                raise ValueError("`out` arrays must be C-contiguous")
+        if on_dev:
+            for a in (data, data_err, data_mask):
+                if tuple(a.shape) != tuple(data.shape) or not a.is_contiguous() or str(a.dtype) != 'torch.float64':
+                    raise ValueError("device objects must be contiguous float64 tensors of one (Ndata, Nfilt) shape")
+            x, xe, xm, obj = data, data_err, data_mask, None
+        else:
+            obj = HostObjects(data, data_err, data_mask)
+            x, xe, xm = obj.x, obj.xe, obj.xm
+        k, lp_norm, dbound = self.search
+        if Ndata:
+            eng.knn_search_fit_predict(q, x, xe, xm, k, lp_norm, dbound, self.opts, self.ko,
+                                       self.prior.chunk(0, Ndata, Ndata) if self.prior is not None else None,
+                                       pdfs=pdfs, lmap=lmap, levid=levid, n=Ndata)
+        if obj is not None:
+            obj.writeback()
+        return pdfs, lmap, levid
 
 
 class NearestNeighbors():
@@ -150,24 +217,10 @@ class NearestNeighbors():
 
     def _run(self, eng, obj, q, lo, hi, opts, ko, track_scale, save_fits, pdfs=None, lmap=None, levid=None,
              prior=None):
-        """search + subset likelihood (+ PDFs) for objects [lo,hi)."""
-        n, W = hi - lo, self.K * self.k
-        idx = np.empty((n, W), dtype=np.int64)
-        eng.knn_query(q[lo:hi], self.k, self.dbound, idx, n=n, lp_norm=self.lp_norm)
-        if prior is not None:
-            # additive ln-prior (pdf.logprob_prior): the three probability planes come from the device
-            kw = {}
-            if save_fits:
-                sl = slice(lo, hi)
-                free = bool(opts.free_scale)
-                kw = dict(neighbors=self.neighbors[sl], nnbr=self.Nneighbors[sl], lnprior=self.fit_lnprior[sl],
-                          lnlike=self.fit_lnlike[sl], lnprob=self.fit_lnprob[sl], chi2=self.fit_chi2[sl],
-                          ndim=self.fit_Ndim[sl],
-                          scale=self.fit_scale[sl] if (track_scale and free) else None,
-                          scale_err=self.fit_scale_err[sl] if (track_scale and free) else None)
-            eng.knn_fit_predict_prior(obj.x[lo:hi], obj.xe[lo:hi], obj.xm[lo:hi], idx, W, opts, ko,
-                                      prior.chunk(lo, hi, len(obj.x)), pdfs=pdfs, lmap=lmap, levid=levid, n=n, **kw)
-            return idx
+        """search + subset likelihood (+ PDFs) for objects [lo,hi): ONE library call (fz_knn_search_fit_predict_prior), the
+        (n, K*k) neighbour table of knn.py:834-837 stays on the device between the K searches and the subset kernel -- it
+        only comes back, de-duplicated (knn.py:840), as ``self.neighbors`` when fits are stored."""
+        n = hi - lo
         kw = {}
         if save_fits:
             sl = slice(lo, hi)
@@ -176,18 +229,21 @@ class NearestNeighbors():
                       chi2=self.fit_chi2[sl], ndim=self.fit_Ndim[sl],
                       scale=self.fit_scale[sl] if (track_scale and free) else None,
                       scale_err=self.fit_scale_err[sl] if (track_scale and free) else None)
-        eng.knn_fit_predict(obj.x[lo:hi], obj.xe[lo:hi], obj.xm[lo:hi], idx, W, opts, ko, pdfs=pdfs, lmap=lmap,
-                            levid=levid, n=n, **kw)
-        if save_fits:
-            sl = slice(lo, hi)
+            if prior is not None:
+                # additive ln-prior (pdf.logprob_prior): the three probability planes come from the device
+                kw.update(lnprior=self.fit_lnprior[sl], lnprob=self.fit_lnprob[sl])
+        eng.knn_search_fit_predict(q[lo:hi], obj.x[lo:hi], obj.xe[lo:hi], obj.xm[lo:hi], self.k, self.lp_norm, self.dbound,
+                                   opts, ko, prior.chunk(lo, hi, len(obj.x)) if prior is not None else None,
+                                   pdfs=pdfs, lmap=lmap, levid=levid, n=n, **kw)
+        if save_fits and prior is None:
+            W = self.K * self.k
             self.fit_lnprob[sl] = self.fit_lnlike[sl]
             valid = np.arange(W)[None, :] < self.Nneighbors[sl][:, None]
             self.fit_lnprior[sl] = np.where(valid, 0.0, -np.inf)          # knn.py:852: zeros on the subset
-        return idx
 
     def _host_run(self, host, data, data_err, data_mask, rstate, track_scale, labels=None):
-        """knn.py:355-388 / 826-874 with a user ``lprob_func``: the K searches and the first-appearance
-        de-duplication run on the GPU (on copies: only the user's callable may touch the caller's rows),
+        """knn.py:355-388 / 826-874 with a user ``lprob_func``: the K searches run on the GPU, the
+        first-appearance de-duplication (``pandas.unique``, knn.py:840) on the host,
         the callable is evaluated per object on its neighbour subset like the reference does, and -- with
         ``labels = (model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)`` -- the PDFs come
         from the GPU out of the stored ln-posterior rows.  Fills the padded ``fit_*`` arrays."""
@@ -311,7 +367,7 @@ class NearestNeighbors():
         ko = kde_opts(kde_kwargs)
         Ndata = self.NDATA
         W = self.neighbors.shape[1]
-        pdfs = np.zeros((Ndata, Nx))
+        pdfs = pinned_empty((Ndata, Nx))
         lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
         lw = np.ascontiguousarray(logwt, dtype=np.float64)
         nb = np.ascontiguousarray(self.neighbors, dtype=np.int64)
@@ -340,8 +396,15 @@ class NearestNeighbors():
     def fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs, lprob_func=None,
                     rstate=None, k=20, eps=1e-3, lp_norm=2, distance_upper_bound=np.inf, label_dict=None,
                     label_grid=None, kde_args=None, kde_kwargs=None, lprob_args=None, lprob_kwargs=None,
-                    return_gof=False, track_scale=False, verbose=True, save_fits=True):
-        """knn.py:560-720."""
+                    return_gof=False, track_scale=False, verbose=True, save_fits=True, out=None,
+                    query_features=None):
+        """knn.py:560-720.
+
+        Extensions (no reference counterpart): ``out=(pdfs, lmap, levid)`` -- caller-allocated float64 arrays, NumPy or
+        tensors on this engine's GPU -- receives the results in place; ``data`` / ``data_err`` / ``data_mask`` may be
+        device tensors; ``query_features`` (Ndata, Nfilt) -- the objects' Monte-Carlo features of knn.py:830-832, NumPy or
+        device tensor -- replaces the draw from ``rstate`` (a driver that shards the objects draws them once for all
+        ranks).  With device tensors throughout nothing crosses PCIe: query features, neighbour table and PDFs stay in HBM."""
         prior, host = _check_lprob(lprob_func, lprob_args, self.NMODEL, lprob_kwargs)
         kde_kwargs = merge_kde_args(kde_args, kde_kwargs, label_dict is not None)
         if label_dict is None and label_grid is None:
@@ -349,6 +412,16 @@ class NearestNeighbors():
         if rstate is None:
             rstate = np.random
         self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        if out is not None or query_features is not None or hasattr(data, "data_ptr"):
+            if host is not None or (save_fits and (out is not None or hasattr(data, "data_ptr"))):
+                raise NotImplementedError("device tensors / `out=` need the built-in likelihood and save_fits=False "
+                                          "(the fit_* arrays are host arrays)")
+            if not save_fits:
+                prep = self.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
+                                                kde_kwargs=kde_kwargs, lprob_kwargs=lprob_kwargs, prior=prior, k=k, eps=eps,
+                                                lp_norm=lp_norm, distance_upper_bound=distance_upper_bound)
+                pdfs, lmap, levid = prep.run(data, data_err, data_mask, out=out, query_features=query_features, rstate=rstate)
+                return (pdfs, (lmap, levid)) if return_gof else pdfs
         if host is not None:
             keep = self if save_fits else copy.copy(self)
             pdfs, gof = keep._host_run(host, data, data_err, data_mask, rstate, track_scale,
@@ -362,10 +435,11 @@ class NearestNeighbors():
         ko = kde_opts(kde_kwargs)
         eng = self._engine()
         Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
-        q = self._query_features(np.asarray(data), np.asarray(data_err), rstate)
+        q = (np.ascontiguousarray(query_features, dtype=np.float64) if query_features is not None
+             else self._query_features(np.asarray(data), np.asarray(data_err), rstate))
         obj = HostObjects(data, data_err, data_mask)
         Ndata = len(obj.x)
-        pdfs = np.zeros((Ndata, Nx))
+        pdfs = pinned_empty((Ndata, Nx))
         lmap, levid = np.zeros(Ndata), np.zeros(Ndata)
         if save_fits:
             self.NDATA = Ndata
@@ -379,6 +453,20 @@ class NearestNeighbors():
         if return_gof:
             return pdfs, (lmap, levid)
         return pdfs
+
+    def prepare_fit_predict(self, model_labels, model_label_errs, label_dict=None, label_grid=None, kde_kwargs=None,
+                            lprob_kwargs=None, prior=None, k=20, eps=1e-3, lp_norm=2, distance_upper_bound=np.inf):
+        """Extension (twin of ``BruteForce.prepare_fit_predict``): model set, feature sets, dictionary and labels on the
+        device and the option structs of one ``fit_predict(save_fits=False)`` configuration, done once; the returned
+        ``run(data, data_err, data_mask, out=, query_features=)`` only moves objects."""
+        if label_dict is None and label_grid is None:
+            raise ValueError("`label_dict` or `label_grid` must be specified.")
+        self._search_setup(k, eps, lp_norm, distance_upper_bound)
+        opts = like_opts(lprob_kwargs)
+        ko = kde_opts(kde_kwargs)
+        eng = self._engine()
+        Nx = eng.set_labels(model_labels, model_label_errs, label_dict, label_grid, kde_kwargs)
+        return _PreparedKnn(self, eng, opts, ko, Nx, prior, (model_labels, model_label_errs, label_dict, label_grid, kde_kwargs))
 
     def _fit_predict(self, data, data_err, data_mask, model_labels, model_label_errs, lprob_func=None,
                      rstate=None, label_dict=None, label_grid=None, kde_args=None, kde_kwargs=None,

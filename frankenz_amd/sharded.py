@@ -8,8 +8,8 @@ PDF depend on that object and the (replicated, ~12 MB) model set alone
 the compute.  What can be exchanged afterwards:
 
   * ``gather='pdfs'``  : all-gather of the (N/P, Nx) PDF shards -> the full (N, Nx)
-                         array on every rank.  For BruteForce the gather is OVERLAPPED with the
-                         compute (``_overlapped``): a rank's objects are dealt out block-cyclically
+                         array on every rank.  With ``save_fits=False`` (BruteForce and NearestNeighbors) the
+                         gather is OVERLAPPED with the compute (``_overlapped``): a rank's objects are dealt out block-cyclically
                          in ``chunks`` rounds, round c's PDFs are written by the kernel straight into
                          their rows of the full device array and leave on RCCL's stream (in-place
                          ``all_gather_into_tensor``, ``async_op``) while round c + 1 is computed; one
@@ -104,13 +104,18 @@ def allreduce_sum(vec, group=None):
 last_stats = {}        # timing of the last overlapped call on this rank (ms_compute, ms_total, ms_gather_exposed, bytes, ...)
 
 
-def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs):
-    """BruteForce.fit_predict over all ranks with the PDF all-gather hidden behind the compute.
+def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs, rstate=None):
+    """``fit_predict`` (BruteForce, or NearestNeighbors) over all ranks with the PDF all-gather hidden behind the compute.
 
     Object i belongs to round c = i // (P cs) and rank r = (i // cs) % P (cs = ceil(N / (P chunks))): the rows a
     round produces are one contiguous (P cs, Nx) slab of the result, rank r's part at offset r cs of it -- which is
     exactly the in-place form of an all-gather, so the kernel's output buffer IS the collective's buffer.
-    (bruteforce.py:602-631: no cross-object state, any assignment of objects to ranks gives the same rows.)"""
+    (bruteforce.py:602-631, knn.py:826-874: no cross-object state, any assignment of objects to ranks gives the same rows;
+    the k-NN variant's per-object Monte-Carlo draws, knn.py:830, are made for ALL objects before the rounds start.)
+
+    Stream contract: the library is told that its inputs come from torch's current stream (``fz_set_producer_stream``), so
+    round c + 1's kernels wait for that stream alone -- NOT for the device, which would drain round c's gather in flight on
+    RCCL's stream and serialise the two (the default wait of a naive caller does exactly that)."""
     import time
     import torch
     dist = _dist()
@@ -120,6 +125,7 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")   # (cpu: the gloo tests' stand-in fitter)
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     was_numpy = isinstance(data, np.ndarray)
+    is_knn = hasattr(fitter, 'KDTrees')
     N = int(data.shape[0])
     label_dict, label_grid = kwargs.get("label_dict"), kwargs.get("label_grid")
     if label_dict is None and label_grid is None:
@@ -129,59 +135,89 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
     def dv(a):
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if isinstance(a, np.ndarray) else a
         return t.to(dev).contiguous()
-    dX, dXe, dXm = dv(data), dv(data_err), dv(data_mask)
-    # the reference cleans every object in place (pdf.py:310-311); every rank holds the full object arrays, so every
-    # rank's copy ends up cleaned, as after the single-process call (N x B values: negligible)
-    sync()                                                      # the library reads the tensors on its own stream
-    if N:
-        fitter._engine().clean(dX, dXe, dXm)
-    C = max(1, int(chunks))
-    cs = max(1, -(-N // (world * C)))
-    C = -(-N // (world * cs))                                   # rounds that hold at least one object
-    rows = C * world * cs
-    pdfs = torch.empty((rows, G), dtype=torch.float64, device=dev)
-    lm = torch.empty(rows, dtype=torch.float64, device=dev)
-    le = torch.empty(rows, dtype=torch.float64, device=dev)
-    extra = set(kwargs) - {"label_dict", "label_grid", "kde_kwargs", "lprob_kwargs", "lprob_func", "lprob_args", "kde_args",
-                           "return_gof", "save_fits", "verbose", "track_scale", "prepared"}
+    known = {"label_dict", "label_grid", "kde_kwargs", "lprob_kwargs", "lprob_func", "lprob_args", "kde_args",
+             "return_gof", "save_fits", "verbose", "track_scale", "prepared"}
+    search = {}
+    if is_knn:
+        known |= {"k", "eps", "lp_norm", "distance_upper_bound", "query_features"}
+        search = {kk: kwargs[kk] for kk in ("k", "eps", "lp_norm", "distance_upper_bound") if kk in kwargs}
+    extra = set(kwargs) - known
     if extra or kwargs.get("kde_args") or kwargs.get("lprob_args"):
-        raise NotImplementedError("sharded_fit_predict (overlapped BruteForce path): unsupported arguments %s" % sorted(extra))
-    # models, dictionary, labels: on the device once, not once per round -- and not at all when the caller hands in the
-    # handle of an earlier ``prepare_fit_predict`` (a driver that calls this function step after step)
-    prep = kwargs.get("prepared")
-    if prep is None:
-        prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
-                                          kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"))
-    works, t_comp = [], 0.0
-    sync()
-    t_start = time.perf_counter()
-    for c in range(C):
-        base = c * world * cs
-        lo = base + rank * cs
-        hi = min(lo + cs, N)
-        if hi > lo:
-            t0 = time.perf_counter()
-            prep.run(dX[lo:hi], dXe[lo:hi], dXm[lo:hi], out=(pdfs[lo:hi], lm[lo:hi], le[lo:hi]))
-            t_comp += time.perf_counter() - t0              # the call returns when the rows are in HBM
-        for buf in (pdfs, lm, le):
-            out_v, in_v = buf[base:base + world * cs], buf[lo:lo + cs]
-            if nccl:
-                try:                                             # in place: rank r's rows already sit at offset r cs of the slab
-                    works.append(dist.all_gather_into_tensor(out_v, in_v, group=group, async_op=True))
-                except (RuntimeError, ValueError):               # a build that refuses overlapping views: one copy of the rank's rows
-                    works.append(dist.all_gather_into_tensor(out_v, in_v.clone(), group=group, async_op=True))
-            else:                                                # gloo (tests, several ranks on one GPU): through host memory
-                tmp = torch.empty(out_v.shape, dtype=out_v.dtype)
-                dist.all_gather_into_tensor(tmp, in_v.cpu(), group=group)
-                out_v.copy_(tmp)
-    for w in works:
-        w.wait()
-    sync()
-    t_total = time.perf_counter() - t_start
+        raise NotImplementedError("sharded_fit_predict (overlapped path): unsupported arguments %s" % sorted(extra))
+    dQ = None
+    if is_knn:
+        # knn.py:830-832 for EVERY object before the objects are dealt out: the random stream -- and so the result -- does not
+        # depend on the number of ranks.  (N x B values on the host; a driver that calls step after step passes them in.)
+        q = kwargs.get("query_features")
+        if q is None:
+            hx, hxe = (np.asarray(data), np.asarray(data_err)) if was_numpy else (data.cpu().numpy(), data_err.cpu().numpy())
+            q = fitter._query_features(hx, hxe, rstate if rstate is not None else np.random)
+        dQ = dv(q)
+    dX, dXe, dXm = dv(data), dv(data_err), dv(data_mask)
+    eng = fitter._engine()
+    lib_stream = on_gpu and hasattr(eng, "set_producer_stream")
+    if lib_stream:
+        eng.set_producer_stream(torch.cuda.current_stream().cuda_stream, 1)
+    try:
+        # the reference cleans every object in place (pdf.py:310-311); every rank holds the full object arrays, so every
+        # rank's copy ends up cleaned, as after the single-process call (N x B values: negligible)
+        if not lib_stream:
+            sync()                                                  # (stand-in fitters: the tensors are read on another stream)
+        if N:
+            eng.clean(dX, dXe, dXm)
+        C = max(1, int(chunks))
+        cs = max(1, -(-N // (world * C)))
+        C = -(-N // (world * cs))                                   # rounds that hold at least one object
+        rows = C * world * cs
+        pdfs = torch.empty((rows, G), dtype=torch.float64, device=dev)
+        lm = torch.empty(rows, dtype=torch.float64, device=dev)
+        le = torch.empty(rows, dtype=torch.float64, device=dev)
+        # models, dictionary, labels (feature sets): on the device once, not once per round -- and not at all when the caller
+        # hands in the handle of an earlier ``prepare_fit_predict`` (a driver that calls this function step after step)
+        prep = kwargs.get("prepared")
+        if prep is None:
+            prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
+                                              kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"), **search)
+        works, t_comp = [], 0.0
+        sync()
+        t_start = time.perf_counter()
+        for c in range(C):
+            base = c * world * cs
+            lo = base + rank * cs
+            hi = min(lo + cs, N)
+            if hi > lo:
+                t0 = time.perf_counter()
+                if is_knn:
+                    prep.run(dX[lo:hi], dXe[lo:hi], dXm[lo:hi], out=(pdfs[lo:hi], lm[lo:hi], le[lo:hi]), query_features=dQ[lo:hi])
+                else:
+                    prep.run(dX[lo:hi], dXe[lo:hi], dXm[lo:hi], out=(pdfs[lo:hi], lm[lo:hi], le[lo:hi]))
+                t_comp += time.perf_counter() - t0              # the call returns when the rows are in HBM; it waits for nothing else
+            for buf in (pdfs, lm, le):
+                out_v, in_v = buf[base:base + world * cs], buf[lo:lo + cs]
+                if nccl:
+                    try:                                             # in place: rank r's rows already sit at offset r cs of the slab
+                        works.append(dist.all_gather_into_tensor(out_v, in_v, group=group, async_op=True))
+                    except (RuntimeError, ValueError):               # a build that refuses overlapping views: one copy of the rank's rows
+                        works.append(dist.all_gather_into_tensor(out_v, in_v.clone(), group=group, async_op=True))
+                else:                                                # gloo (tests, several ranks on one GPU): through host memory
+                    tmp = torch.empty(out_v.shape, dtype=out_v.dtype)
+                    dist.all_gather_into_tensor(tmp, in_v.cpu(), group=group)
+                    out_v.copy_(tmp)
+        t_fence0 = time.perf_counter()
+        for w in works:
+            w.wait()
+        sync()
+        t_end = time.perf_counter()
+    finally:
+        if lib_stream:
+            eng.set_producer_stream(None, 0)
+    t_total = t_end - t_start
     nbytes = rows * G * 8
     last_stats.clear()
+    # ms_compute: host time inside the library calls (kernels + launches; with the stream contract it contains no wait for the
+    # collective); ms_fence: what the final fence waited for = the part of the gathers that the compute did not cover
     last_stats.update(ms_compute=t_comp * 1e3, ms_total=t_total * 1e3, ms_gather_exposed=(t_total - t_comp) * 1e3,
-                      chunks=C, rows_per_chunk=cs, bytes_gathered=nbytes, world=world,
+                      ms_fence=(t_end - t_fence0) * 1e3, chunks=C, rows_per_chunk=cs, bytes_gathered=nbytes, world=world,
                       busbw_GBs_if_serial=None)
     if was_numpy:
         for src, dst in ((dX, data), (dXe, data_err), (dXm, data_mask)):
@@ -205,25 +241,29 @@ def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_l
     world = dist.get_world_size(group) if dist is not None else 1
     rank = dist.get_rank(group) if dist is not None else 0
     n = len(data)
-    if (gather == 'pdfs' and dist is not None and world > 1 and not hasattr(fitter, 'KDTrees') and chunks
-            and kwargs.get('lprob_func') is None and not kwargs.get('save_fits', False)
+    # the reference's default is save_fits=True (bruteforce.py:374-378, knn.py:560-563): only an EXPLICIT save_fits=False takes the
+    # device-resident path, which has no fit_* arrays to fill
+    if (gather == 'pdfs' and dist is not None and world > 1 and chunks
+            and kwargs.get('lprob_func') is None and kwargs.get('save_fits', True) is False
             and (_gpu_ok() or getattr(fitter, 'accepts_tensors', False))):
-        # BruteForce with the built-in likelihood: device-resident, the gather overlapped with the compute
-        # (pass save_fits=False; the fit_* planes would be host arrays of the local block)
-        return _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs)
+        # built-in likelihood: device-resident, the gather overlapped with the compute (BruteForce and NearestNeighbors alike)
+        return _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_errs, group, chunks, kwargs, rstate)
     if hasattr(data, "data_ptr"):
-        raise NotImplementedError("device tensors are taken by the overlapped BruteForce path only "
+        raise NotImplementedError("device tensors are taken by the overlapped path only "
                                   "(gather='pdfs', save_fits=False, built-in likelihood)")
     sl = shard_slice(n, world, rank)
     kwargs = dict(kwargs, return_gof=True)
     kwargs.setdefault('verbose', False)
     if hasattr(fitter, 'KDTrees'):
-        # k-NN: draw the Monte-Carlo realisation of EVERY object, then hand this rank a
-        # generator that replays only its rows (knn.py:830 consumes B normals per object)
-        if rstate is None:
-            rstate = np.random
-        draws = rstate.normal(np.asarray(data), np.asarray(data_err))
-        kwargs['rstate'] = _Replay(draws[sl])
+        if kwargs.get('query_features') is not None:
+            kwargs['query_features'] = kwargs['query_features'][sl]         # drawn by the caller for every object
+        else:
+            # k-NN: draw the Monte-Carlo realisation of EVERY object, then hand this rank a
+            # generator that replays only its rows (knn.py:830 consumes B normals per object)
+            if rstate is None:
+                rstate = np.random
+            draws = rstate.normal(np.asarray(data), np.asarray(data_err))
+            kwargs['rstate'] = _Replay(draws[sl])
     pdfs, (lmap, levid) = fitter.fit_predict(data[sl], data_err[sl], data_mask[sl], model_labels,
                                              model_label_errs, **kwargs)
     if gather == 'pdfs':

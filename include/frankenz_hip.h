@@ -16,12 +16,15 @@
  *    the library detects which (hipPointerGetAttributes) and stages host arrays
  *    through its own buffers.  Output pointers may be NULL = "not wanted".
  *  - masks are float64 0/1 (the reference's demos use np.ones_like(phot)).
- *  - STREAM ORDERING.  The library runs on a stream of its own.  An entry point that is
- *    handed device pointers first waits for ALL work queued on the device so far
+ *  - STREAM ORDERING.  The library runs on a stream of its own.  By default an entry point
+ *    that is handed device pointers first waits for ALL work queued on the device so far
  *    (hipDeviceSynchronize), so inputs produced by kernels on any caller stream are
  *    complete before they are read; and every entry point returns only when its own
  *    work has finished, so outputs may be consumed from any stream at once.  No
- *    caller-side synchronisation is needed on either side of a call.
+ *    caller-side synchronisation is needed on either side of a call.  A caller that
+ *    overlaps the library with other device work (an RCCL all-gather of the previous
+ *    block's rows in flight) names the stream its inputs are produced on instead --
+ *    fz_set_producer_stream -- and the library waits for that stream alone.
  *  - one fz_ctx per device; a ctx is not thread-safe.
  */
 #ifndef FRANKENZ_HIP_H
@@ -94,6 +97,18 @@ const char* fz_last_form(fz_ctx* ctx);
 /* byte budget for internal work space (candidate lists of the single-pass kernel, (N x M)
  * planes of mode C, host staging); default 45 % of the device memory, allocated on demand. */
 int  fz_set_workspace_limit(fz_ctx* ctx, int64_t bytes);
+/* Where device-resident INPUTS of the following calls come from (no reference counterpart: the reference has no device).
+ * mode 0 (default): unknown -- every entry point handed device pointers drains the whole device first (hipDeviceSynchronize).
+ * mode 1: they are produced by work queued on `stream` (a hipStream_t; NULL = the legacy default stream): the library records an
+ *         event there and makes ITS stream wait for it -- no host wait, and work on other streams (a collective in flight) is
+ *         not waited for.
+ * mode 2: they are complete (the caller has synchronised): no wait at all.
+ * Outputs are complete when a call returns in every mode. */
+int  fz_set_producer_stream(fz_ctx* ctx, void* stream, int32_t mode);
+/* page-locked host memory (hipHostMalloc) for results: device-to-host copies into it run at the link rate and overlap the next
+ * chunk's kernel, which copies into pageable memory (np.zeros) do not.  The drop-in classes return their PDF arrays in it. */
+int  fz_host_alloc(int64_t bytes, void** out);
+int  fz_host_free(void* p);
 
 /* BruteForce.__init__ (bruteforce.py:36-64): the model set (M,B) x3. */
 int  fz_models_upload(fz_ctx* ctx, const double* models, const double* models_err,
@@ -131,6 +146,14 @@ int  fz_fit(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
 int  fz_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
                     const fz_like_opts* opts, const fz_kde_opts* kde,
                     double* pdfs, double* lmap, double* levid);
+
+/* mode C (pdf.py:196-223) bookkeeping since the last fz_timing_reset, out4 = {objects whose stop decision fell within rounding
+ * of ltol under the reciprocal-based solve and were re-run with IEEE divisions, iterations of the slowest object, 1 = one block
+ * per object / 2 = state planes in HBM, threads per block of the former}; and the number of passes of the loop at pdf.py:199
+ * each of the first n objects of the LAST mode-C chunk took (int32, host) -- the reference does not return it, the tests compare
+ * it with their restated loop. */
+int  fz_modec_info(fz_ctx* ctx, int64_t* out4);
+int  fz_modec_niter(fz_ctx* ctx, int64_t n, int32_t* out);
 
 /* ---- additive ln-prior (extension) ----
  * The reference's plug-in point is lprob_func, called once per object and returning
@@ -190,6 +213,16 @@ int  fz_knn_fit_predict_prior(fz_ctx* ctx, double* x, double* xe, double* xm, in
                               int64_t* nnbr, double* lnprior, double* lnlike, double* lnprob,
                               double* chi2, int64_t* ndim, double* scale, double* scale_err,
                               double* pdfs, double* lmap, double* levid);
+
+/* NearestNeighbors._fit_predict (knn.py:826-874) in one call: fz_knn_query + fz_knn_fit_predict_prior over chunks of <= 2^17
+ * objects with the (N, K*k) neighbour table kept on the device (it only leaves through `neighbors`, if wanted).  q (N,F): the
+ * objects' query features (knn.py:830-832), drawn by the caller so that the random stream is the reference's. */
+int  fz_knn_search_fit_predict_prior(fz_ctx* ctx, const double* q, double* x, double* xe, double* xm, int64_t N,
+                                     int32_t k, double lp_norm, double distance_upper_bound,
+                                     const fz_like_opts* opts, const fz_kde_opts* kde, const fz_prior* prior,
+                                     int64_t* neighbors, int64_t* nnbr, double* lnprior, double* lnlike,
+                                     double* lnprob, double* chi2, int64_t* ndim, double* scale,
+                                     double* scale_err, double* pdfs, double* lmap, double* levid);
 
 /* NearestNeighbors._predict (knn.py:488-558): PDFs from stored (N,W) ln-weights,
  * the stored neighbour table (N,W) and counts (N). */

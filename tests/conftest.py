@@ -12,10 +12,12 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
 # ln-evidence.  Two tolerances, by what the path under test computes:
-#   EVID   -- the DEFAULT bodies of the fused fit_predict and of predict-from-stored-weights on mask-free data with the
-#             dimensionality prior and no ln-prior (k_hist<screen>, k_fused's weight-space body, k_plane_fused<X32>): the share
-#             of every model within wt_thresh of the best is summed in fp64, the rest (each below wt_thresh of the best) in
-#             fp32.  ~1e-9 observed, bounded by ~1e-6 relative on that remainder; north_star's bar is 1e-5.
+#   EVID   -- k_fused's weight-space body (many dictionary kernel widths, the direct grid KDE, FZ_HIST=0) and k_plane_fused<X32>
+#             (stored rows too long for k_plane_rows): the share of every model within wt_thresh of the best is summed in fp64, the
+#             rest (each below wt_thresh of the best) in fp32.  ~1e-9 observed, bounded by ~1e-6 relative on that remainder;
+#             north_star's bar is 1e-5.  Tests that cover several routes at once also hold this one.
+#             (Since round 4 the default fused kernel, k_hist, is fp64 throughout: test_default_fused_evidence_is_the_fp64_logsumexp
+#             holds it to 1e-12.)
 #   EVID64 -- every all-fp64 path: exact_evidence=True (lprob_kwargs / kde_kwargs), masked objects or models, padded band
 #             counts, wild values (IEEE variant), ln-priors, the Gaussian likelihood, the CDF rule, mode C's materialised rows,
 #             the two-pass kernels.  A regression of 1e-8 in any of these fails.

@@ -131,6 +131,53 @@ def g2():
     save('g2_modec', **out)
 
 
+class _CountingNumpy(object):
+    """numpy as the reference's pdf module sees it, counting ``np.log`` calls on arrays: _loglike_s takes ONE such log per solve
+    (the log-variance sum of pdf.py:193-194 / 216-217), so calls - 1 = passes of the loop at pdf.py:199 -- the iteration
+    count the reference does not return, read off the reference itself."""
+
+    def __init__(self):
+        self.n = 0
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def log(self, v):
+        if isinstance(v, np.ndarray):
+            self.n += 1
+        return np.log(v)
+
+
+def g2b():
+    """mode C at the BENCHMARKED size: M = 10 000 models (the launch shape the 2e4 x 1e4 line runs), heterogeneous model errors,
+    3 objects x {ltol 1e-4, 1e-8}, dimensionality prior on; outputs of the reference AND its iteration counts."""
+    rs = np.random.RandomState(2222)
+    M, B = 10000, 5
+    Y, _ = mock_models(rs, M, B)
+    Ye = Y * rs.uniform(0.01, 0.12, size=(M, B))
+    Ym = np.ones((M, B))
+    X = np.array([Y[171] * 1.7 + SDSS_SIGMA * rs.randn(B),
+                  Y[4000] * 0.4 + SDSS_SIGMA * rs.randn(B),
+                  12. * Y[9200] + SDSS_SIGMA * rs.randn(B)])
+    Xe = np.tile(SDSS_SIGMA, (3, 1))
+    Xm = np.ones((3, B))
+    out = dict(Y=Y, Ye=Ye, X=X, Xe=Xe)
+    proxy, saved = _CountingNumpy(), rpdf.np
+    rpdf.np = proxy
+    try:
+        for oi in range(3):
+            for tname, ltol in (('t4', 1e-4), ('t8', 1e-8)):
+                proxy.n = 0
+                res = rpdf.loglike(X[oi].copy(), Xe[oi].copy(), Xm[oi].copy(), Y, Ye, Ym, free_scale=True,
+                                   ignore_model_err=False, dim_prior=True, ltol=ltol, return_scale=True)
+                k = 'o%d_%s' % (oi, tname)
+                out[k + '_lnl'], out[k + '_scale'] = res[0], res[3]
+                out[k + '_niter'] = np.array(proxy.n - 1)
+    finally:
+        rpdf.np = saved
+    save('g2b_modec_10k', **out)
+
+
 def demo_dict():
     return rpdf.PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
 
@@ -603,6 +650,6 @@ if __name__ == '__main__':
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
-    which = sys.argv[1:] or ['g%d' % k for k in range(1, 14)]
+    which = sys.argv[1:] or (['g%d' % k for k in range(1, 14)] + ['g2b'])
     for name in which:
         globals()[name]()

@@ -495,6 +495,33 @@ def test_tuning_switches_do_not_change_results(env, monkeypatch):
 
 
 @pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
+@pytest.mark.parametrize('err', ['const', 'varying'])
+def test_default_fused_evidence_is_the_fp64_logsumexp(kw, err):
+    """The DEFAULT fused path (k_hist) forms and sums every weight in fp64 -- the fp32 quantity only classifies which pairs can
+    matter at all (below 2^-(55 + log2 M) of the best: dropped) -- so its ln-evidence is the reference's fp64 logsumexp
+    (bruteforce.py:619) to rounding: 1e-12 here, against the oracle, on data whose sub-threshold pairs carry a large share of the
+    evidence (broad noise) and on narrow likelihoods; ln-max and PDFs likewise."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    for noise in (1.0, 4.0):
+        rs = np.random.RandomState(int(77 + 10 * noise))
+        M, N, B = 9000, 120, 5
+        sig = SDSS5 * noise
+        Y = rs.lognormal(1., 1., size=(M, B)); Ym = np.ones((M, B))
+        Ye = np.tile(sig, (M, 1)) if err == 'const' else sig * rs.uniform(0.5, 1.5, size=(M, B))
+        X = Y[rs.choice(M, N)] + sig * rs.randn(N, B); Xe = np.tile(sig, (N, 1)); Xm = np.ones((N, B))
+        z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+        p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                        return_gof=True, save_fits=False, verbose=False)
+        assert get_engine().last_form().startswith('k_hist<')
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+        close(le, rle, rtol=1e-12, atol=1e-12)
+        close(lm, rlm, rtol=1e-12, atol=1e-12)
+        close(p, rp, rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}, {'free_scale': True, 'ignore_model_err': True}])
 def test_exact_evidence_switch(kw, monkeypatch):
     """The default weight-space body sums the sub-threshold weights in fp32 (EVID); FZ_NO_WSPACE=1
     selects the all-fp64 ln-space body, whose ln-evidence is held to 1e-9 here, and the two bodies
@@ -924,7 +951,7 @@ def test_uploads_are_remembered_by_content_and_in_place_edits_are_seen():
 @pytest.mark.parametrize('B', [9, 12, 16, 20, 32])
 @pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True}, {'ignore_model_err': True}])
 @pytest.mark.parametrize('err', ['const', 'varying'])
-def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err):
+def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err, monkeypatch):
     """9-32 real bands without masks (the reference's COSMOS list holds 32 filters): the one-pass histogram kernel in its mask-free
     form on the 16- / 32-band instantiations (pad bands are zeros; the power of chi2 is that of the real band count), one object
     per wave and eight waves per block -- against the oracle, default and all-fp64 evidence."""
@@ -944,13 +971,17 @@ def test_wide_band_sets_on_the_one_pass_kernel(B, kw, err):
     bf = BruteForce(Y, Ye, Ym)
     general32 = (B > 16 and err == 'varying' and not kw)           # 17-32 bands with per-model errors: no room in the register file, masked kernels
     for exact in (False, True):
-        lk = dict(kw, exact_evidence=True) if exact else kw
-        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=lk, return_gof=True,
-                                     verbose=False, save_fits=False)
+        # both forms of k_hist are fp64 throughout: the classifier form (default) and the one that weighs every pair directly
+        # (FZ_EXACT_EVIDENCE=1; what the free scale and broad likelihoods run anyway)
+        with monkeypatch.context() as mp:
+            if exact:
+                mp.setenv('FZ_EXACT_EVIDENCE', '1')
+            p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True,
+                                         verbose=False, save_fits=False)
         form = get_engine().last_form()
-        assert form == ('k_fused' if general32 else ('k_hist<exact>' if exact else 'k_hist<screen>')), form
+        assert form == ('k_fused' if general32 else ('k_hist<exact>' if (exact or kw.get('free_scale')) else 'k_hist<screen>')), form
         close(p, rp, rtol=1e-7, atol=1e-13); close(lm, rlm, rtol=1e-9)
-        close(le, rle, **(EVID64 if exact or general32 else EVID))
+        close(le, rle, **EVID64)
 
 
 @pytest.mark.parametrize('M', [4100, 5120, 10000, 10240, 17000, 20480])
@@ -1051,11 +1082,11 @@ def test_objects_with_unobserved_bands_on_the_one_pass_kernel(B, kw, monkeypatch
     run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
     with np.errstate(all='ignore'):
         p0, (lm0, le0) = run()
-        if not (B == 8 and kw.get('free_scale')):                      # (8 bands with the free scale: the buffers of the closed-form screen do not fit the LDS beside 16 histogram rows)
-            assert get_engine().last_form() == 'k_hist<screen> (per-object band counts)'
+        # (the free scale runs the form that weighs every pair directly; both are fp64 throughout)
+        assert get_engine().last_form() == ('k_hist<exact> (per-object band counts)' if kw.get('free_scale') else 'k_hist<screen> (per-object band counts)')
         monkeypatch.setenv('FZ_HIST_OBJMASK', '0')
         p1, (lm1, le1) = run()
-        assert get_engine().last_form() != 'k_hist<screen> (per-object band counts)'
+        assert not get_engine().last_form().endswith('(per-object band counts)')
         monkeypatch.delenv('FZ_HIST_OBJMASK')
         rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
     # one observed band with the free scale: zero degrees of freedom, ln-like = (+-inf or a rounding-sized log) - gammaln(0): nan or
@@ -1065,7 +1096,7 @@ def test_objects_with_unobserved_bands_on_the_one_pass_kernel(B, kw, monkeypatch
     if kw.get('free_scale'):
         ok[Xm.sum(axis=1) <= 1] = False
         assert np.all(~np.isfinite(lm0[~ok])) and np.all(~np.isfinite(rlm[~ok]))
-    close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0[ok], rlm[ok], rtol=1e-9); close(le0[ok], rle[ok], **EVID)
+    close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0[ok], rlm[ok], rtol=1e-9); close(le0[ok], rle[ok], **EVID64)
     close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)
 
 
@@ -1086,11 +1117,11 @@ def test_no_dimensionality_prior_on_the_power_zero_form(kw, monkeypatch):
         run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
         with np.errstate(all='ignore'):
             p0, (lm0, le0) = run()
-            assert get_engine().last_form().startswith('k_hist<screen>')
+            assert get_engine().last_form().startswith('k_hist<exact>' if kw.get('free_scale') else 'k_hist<screen>')
             monkeypatch.setenv('FZ_HIST_NODIMPRIOR', '0'); monkeypatch.setenv('FZ_HIST_OBJMASK', '0')
             p1, (lm1, le1) = run()
             assert not get_engine().last_form().startswith('k_hist')
             monkeypatch.delenv('FZ_HIST_NODIMPRIOR'); monkeypatch.delenv('FZ_HIST_OBJMASK')
             rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
-        close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0, rlm, rtol=1e-9); close(le0, rle, **EVID)
+        close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0, rlm, rtol=1e-9); close(le0, rle, **EVID64)
         close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)

@@ -60,6 +60,21 @@ def test_g1_logprob_adapter():
     assert len(r) == 5
 
 
+def test_g2b_mode_c_iteration_counts_of_the_reference_at_the_benchmarked_size():
+    """G2b: M = 10 000, the reference's outputs and the number of passes its loop at pdf.py:199 took (counted on the reference
+    itself by make_golden.py): the oracle's ``return_niter`` is the reference's count, its rows the reference's rows."""
+    g = load_golden('g2b_modec_10k')
+    Y, Ye = g['Y'], g['Ye']
+    for oi in range(2):                      # (object 2 takes 2104 / 4794 passes: the GPU test covers it)
+        for tname, ltol in (('t4', 1e-4), ('t8', 1e-8)):
+            r = fo.lnlike_scaled(g['X'][oi].copy(), g['Xe'][oi].copy(), np.ones(5), Y, Ye, np.ones_like(Y), ltol=ltol,
+                                 return_scale=True, return_niter=True)
+            k = 'o%d_%s' % (oi, tname)
+            assert r[5] == int(g[k + '_niter'])
+            eq(r[0], g[k + '_lnl'], rtol=0, atol=0)
+            eq(r[3], g[k + '_scale'], rtol=0, atol=0)
+
+
 def test_g2_mode_c_global_stop_rule():
     g = load_golden('g2_modec')
     Y, Ye, Ym = g['Y'], g['Ye'], g['Ym']

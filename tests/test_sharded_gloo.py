@@ -55,6 +55,88 @@ class OracleBFTensors(OracleBF):
         return _E()
 
 
+class OracleKNN(object):
+    """NearestNeighbors-shaped adapter around the oracle: the k-NN variant on the overlapped path of sharded_fit_predict
+    (``KDTrees`` marks it; the Monte-Carlo query features are drawn for every object before the rounds)"""
+    accepts_tensors = True
+    NDIM = 5
+
+    def __init__(self, Y, Ye, Ym, kd, K=3, k=4):
+        import frankenz_oracle as fo
+        self.Y, self.Ye, self.Ym, self.kd, self.K, self.k = Y, Ye, Ym, kd, K, k
+        self.feats = fo.knn_train(Y, Ye, K, 'luptitude', np.random.RandomState(1))
+        self.KDTrees = [None] * K
+
+    def _query_features(self, x, xe, rstate):
+        import frankenz_oracle as fo
+        return fo.knn_query_features(x, xe, 'luptitude', rstate)
+
+    def reference(self, x, xe, xm, q, z, ze):
+        import frankenz_oracle as fo
+        nb = fo.knn_neighbors_exact(self.feats, q, self.k)
+        return fo.knn_fit_predict(x, xe, xm, self.Y, self.Ye, self.Ym, nb, z, ze, label_dict=self.kd)[:3]
+
+    def prepare_fit_predict(self, z, ze, label_dict=None, k=None, **kw):
+        nn = self
+        assert k == self.k
+
+        class _P(object):
+            @staticmethod
+            def run(x, xe, xm, out=None, query_features=None):
+                import torch
+                p, lm, le = nn.reference(x.numpy(), xe.numpy(), xm.numpy(), query_features.numpy(), z, ze)
+                out[0].copy_(torch.from_numpy(p)); out[1].copy_(torch.from_numpy(lm)); out[2].copy_(torch.from_numpy(le))
+                return out
+        return _P()
+
+    _engine = OracleBFTensors._engine
+
+
+def _knn_worker(rank, world, port, n, q, chunks):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch.distributed as dist
+    import frankenz_oracle as fo
+    from frankenz_amd import sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rs = np.random.RandomState(4)
+    M, B = 90, 5
+    Y = rs.lognormal(1, 1, (M, B)) * 5; Ye = 0.05 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, n)] + 0.3 * rs.randn(n, B); Xe = np.full((n, B), 0.3); Xm = np.ones((n, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    kd = fo.KernelDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    nn = OracleKNN(Y, Ye, Ym, kd)
+    full, (lm, le) = sharded.sharded_fit_predict(nn, X.copy(), Xe.copy(), Xm.copy(), z, ze, gather='pdfs', label_dict=kd, chunks=chunks,
+                                                 save_fits=False, rstate=np.random.RandomState(2), k=nn.k)
+    assert sharded.last_stats['world'] == world
+    # the single-process answer: one (N, B) draw from the same seed, every object
+    qq = nn._query_features(X, Xe, np.random.RandomState(2))
+    ref, rlm, rle = nn.reference(X, Xe, Xm, qq, z, ze)
+    ok = np.array_equal(full, ref) and np.array_equal(lm, rlm) and np.array_equal(le, rle)
+    q.put((rank, bool(ok), full.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n,chunks', [(2, 13, 3), (3, 20, 2)])
+def test_gloo_knn_variant_on_the_overlapped_path(world, n, chunks):
+    """configs[3]'s sharded form: block-cyclic rounds + in-place gather for NearestNeighbors, Monte-Carlo draws made for all
+    objects first (the result does not depend on the rank count)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_knn_worker, args=(r, world, port, n, q, chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (n, 701) for _, _, shape in res)
+
+
 def _worker(rank, world, port, n, q, tensors=False, chunks=4):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import torch.distributed as dist
