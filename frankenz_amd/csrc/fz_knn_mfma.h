@@ -123,6 +123,23 @@ static __global__ __launch_bounds__(64) void k_knn_gboxes(int64_t Mp, float* __r
     for (int u = 0; u < FZ_KM_GT; ++u) if (g0 + u < ntl) base[(g0 + u) * FZ_KM_TSTR + 528 + lane] = v;
 }
 
+// second level of the skipping: boxes of at most 128 groups of 2^gsl consecutive tiles (k-d order: consecutive leaves are subtrees or
+// neighbouring subtrees), [set][128][lo 8 | hi 8].  A wave tests them all at once against its 16 queries' bars (k_knn_mfma: two
+// lane-parallel rounds) and keeps the result as a 128-bit mask in scalar registers; the scan then steps over unreachable groups
+// without touching their tiles' boxes.  Groups past the last tile get an empty box (never reachable).
+static __global__ __launch_bounds__(64) void k_knn_maskboxes(int64_t Mp, int M, int gsl, const float* __restrict__ bmat, float* __restrict__ gbox) {
+    const int lane = threadIdx.x, t = blockIdx.y, g = blockIdx.x;
+    const int64_t ntl = ((int64_t)M + 63) >> 6, t0 = (int64_t)g << gsl, t1 = t0 + ((int64_t)1 << gsl) < ntl ? t0 + ((int64_t)1 << gsl) : ntl;
+    if (lane >= 16) return;
+    const float* base = bmat + (size_t)t * (Mp >> 6) * FZ_KM_TSTR;
+    float v = lane < 8 ? INFINITY : -INFINITY;
+    for (int64_t u = t0; u < t1; ++u) {
+        const float b = base[u * FZ_KM_TSTR + 512 + lane];
+        v = lane < 8 ? fminf(v, b) : fmaxf(v, b);
+    }
+    gbox[((size_t)t * 128 + g) * 16 + lane] = v;          // (no tile: lo = +inf, hi = -inf)
+}
+
 // 12-bit Morton prefix of a feature vector: features quantised to 10 bits inside the set's bounding box (lo, scale),
 // bits interleaved most significant first.  Used to order a set's models (host, at upload), to order the queries
 // (k_knn_qhist / k_knn_qscatter) and to find where a wave's queries sit among a set's models (k_knn_mfma).
@@ -216,17 +233,27 @@ __device__ __forceinline__ float knn_bar_mfma(double tau, float uq2, float e) {
 template <int FL>
 struct KnnScan {
     int nl, nr, ntiles, right;
+    unsigned long long m0, m1;                             // reachable groups of 2^gsl tiles (bit g; wave-uniform), see k_knn_maskboxes
+    int gsl;
     int cand;                                             // this lane's candidate tile of the batch in registers: lane group c = lane >> 4 holds candidate c (-1: none)
     int pend;                                             // ... of the batch that was tested last
     fz_f4 bl0, bl1, bh0, bh1;                             // the candidate's box: lo[0..7], hi[0..7]
     unsigned pmask;                                       // reachable candidates of the tested batch that have not been taken yet
     // (no four-way selects over members here: the compiler turns them into indexed loads and moves the whole struct to scratch)
     __device__ __forceinline__ int next_tile() {
-        if (nr >= ntiles && nl < 0) return -1;
-        int t;
-        if ((right && nr < ntiles) || nl < 0) t = nr++; else t = nl--;
-        right = 1 - right;
-        return t;
+        while (true) {
+            if (nr >= ntiles && nl < 0) return -1;
+            const bool r = (right && nr < ntiles) || nl < 0;
+            const int t = r ? nr : nl;
+            const int g = t >> gsl;                         // < 128
+            const unsigned long long mw = g < 64 ? m0 : m1;
+            if ((mw >> (g & 63)) & 1ull) {
+                if (r) ++nr; else --nl;
+                right = 1 - right;
+                return t;
+            }
+            if (r) nr = (g + 1) << gsl; else nl = (g << gsl) - 1;       // the whole group is out of every row's reach
+        }
     }
     __device__ __forceinline__ void fetch(const float* bm, int sl) {
         int m = -1;
@@ -282,7 +309,8 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                                                          const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
-                                                         const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd, int kdorder) {
+                                                         const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd, int kdorder,
+                                                         const float* __restrict__ gbox, int gsl) {
     static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
     static_assert(KPL == 0 || KPL == 5 || KPL == 8, "register lists: k <= 20 or k <= 32");
     constexpr int TF = FZ_KM_TSTR;
@@ -454,6 +482,34 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     // the per-tile test + staging + barrier was two thirds of the kernel's instructions.)
     KnnScan<FL> sc;
     sc.nl = -1; sc.nr = 0; sc.ntiles = ntiles; sc.right = 1; sc.pmask = 0u; sc.pend = -1;
+    sc.m0 = ~0ull; sc.m1 = ~0ull; sc.gsl = gbox ? gsl : 30;
+    // group mask: lane l tests groups l and l + 64 against all 16 rows (their queries from LDS, their bars from lanes 0..15)
+    auto build_mask = [&]() __attribute__((always_inline)) {
+        if (!gbox) return;
+        unsigned long long mm[2];
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const fz_f4* bx = reinterpret_cast<const fz_f4*>(gbox + ((size_t)tree * 128 + lane + 64 * h) * 16);
+            const fz_f4 l0 = bx[0], l1 = bx[1], h0 = bx[2], h1 = bx[3];
+            bool reach = false;
+#pragma unroll 1
+            for (int R = 0; R < 16; ++R) {
+                const float br = __shfl(barrow, R, 64);
+                float lb = 0.f;
+#pragma unroll
+                for (int f = 0; f < FL; ++f) {
+                    const float qf = (float)qs[wave][R][f], eq = 2.0e-7f * fabsf(qf);
+                    const float lo = f < 4 ? l0[f & 3] : l1[f & 3], hi = f < 4 ? h0[f & 3] : h1[f & 3];
+                    const float m = fmaxf(fmaxf(lo - (qf + eq), (qf - eq) - hi), 0.f);
+                    lb = fmaf(m, m, lb);
+                }
+                reach = reach || (lb * 0.999999f <= br);
+            }
+            mm[h] = __ballot(reach);
+        }
+        sc.m0 = mm[0]; sc.m1 = mm[1];
+    };
+    bool need_mask = seed != nullptr;                    // seeded sets: the bars are near their final values from the start
     if (NWB == 1 && ktab) {
         double qm[8];
 #pragma unroll
@@ -532,6 +588,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         }
     };
     int cur_t = sc.next_reachable(bm, sl, qlo, qhi, barrow);
+    int ndone = 0;
     auto run_tile = [&](const float* cur, float* nxt) __attribute__((always_inline)) -> bool {
         const int nx = sc.next_reachable(bm, sl, qlo, qhi, barrow);     // (tested against the bars as they are now: a superset of what will still matter)
         if (nx >= 0) stage(nx, nxt);
@@ -565,6 +622,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
             }
         }
         cur_t = nx;
+        // the bars have dropped since the mask was built (a cold scan starts with none): again after 8 and after 40 tiles
+        ++ndone;
+        need_mask = need_mask || ndone == 8 || ndone == 40;
         __syncthreads();
         return nx >= 0;
     };
@@ -572,6 +632,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         stage(cur_t, tA);
         __syncthreads();
         while (true) {
+            if (need_mask) { build_mask(); need_mask = false; }      // (the one call site: inlined three times it cost the kernel its occupancy)
             if (!run_tile(tA, tB)) break;
             if (!run_tile(tB, tA)) break;
         }
