@@ -10,22 +10,21 @@
 //   (1) the dimensionality-prior likelihood chi2^(k/2) e^(-chi2/2) / C has its maximum at chi2 = k
 //       whatever the data are, so ln L(k) is an upper bound of every ln-like of every object and can
 //       serve as THE reference of every weight: w = L(chi2) / L(k) <= 1.  No re-basing, no overflow
-//       case; objects whose best weight falls out of fp32's range are handed to the exact ln-space
-//       sweep (k_fused<.., false>), as before.
+//       case; objects whose best weight lies below 2^-400 of the mode's are handed to the exact ln-space
+//       sweep (k_fused<.., false>).
 //   (2) the reference stacks the models with w > wt_thresh * max(w) (pdf.py:591).  max(w) <= 1, so
 //       w > wt_thresh is SUFFICIENT to be stacked and can be decided the moment the pair is seen: its
 //       weight goes straight into the object's LDS histogram (one ds_add_f64 at the label index, the
 //       single-kernel form of the stack).  Only the pairs with wt_thresh * (running best) < w <=
 //       wt_thresh -- a thin band when the best model fits well -- wait in a short per-object list
-//       for the exact maximum.
-// The exact (fp64) weight of a candidate costs ~20 instructions; 7 % of the pairs need it at SDSS depth.
-// A lane that computes it on the spot makes its whole wave pay, so candidates (chi2, label index) are
-// first compacted into a per-object LDS ring and the ring is drained 64 entries at a time by ALL lanes:
-// exact weight, exact evidence share, best chi2 on either side of the mode (the exact maximum, as in
-// k_nl_max), histogram add or the ambiguous list.  The drain's latency overlaps the model loop of
-// the other waves instead of forming a phase of its own.
-// What is fp32: ONLY the classifier.  t = log2 of the pair's weight, to ~1e-5, decides with a margin of 1 (a factor 2) whether the
-// pair can matter at all: a weight below 2^-(55 + ceil log2 M) of the best weight seen SO FAR (hence of the final best) is dropped --
+//       ("ambiguous") for the exact maximum.
+// The exact (fp64) weight of a pair costs ~28 instructions (integer powers by multiplication, the half power by a Newton-refined
+// v_rsq_f64, one table exponential).  A lane that computes it on the spot makes its whole wave pay, so the pairs that can matter
+// (chi2, label index) are first compacted into a per-object LDS buffer and the buffer is drained 64 entries at a time by ALL
+// lanes: exact weight, exact evidence share, the best weight seen (ln-max = ln L(mode) + its ln), histogram add or the ambiguous
+// list.  The drain's latency overlaps the model loop of the other waves instead of forming a phase of its own.
+// What is fp32: ONLY the classifier.  t ~ log2 of the pair's weight (four fp32 instructions, no transcendental: log2 chi2 read off
+// the float's bits, good to +-0.045 K / 2; the margins cover it) decides whether the pair can matter at all: a weight below 2^-(55 + ceil log2 M) of the best weight seen SO FAR (hence of the final best) is dropped --
 // all M of them together change the fp64 sum of the evidence by less than 2^-55 of it, a quarter of its last bit -- and every
 // other pair (41 % on the SDSS-depth benchmark, 7 % of them above wt_thresh) goes through the LDS buffer and gets its weight in
 // fp64, 64 at a time.  No fp32 term enters any sum: ln-evidence, ln-max, stacked weights and PDFs are the fp64 numbers of the
@@ -216,14 +215,26 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     tag_t* rtag = s_tag + (EXACT ? 0 : wave * (TW * CAP));
     Cand* ambw = amb + (size_t)gw * TW * cap;
     // log2 of the screening weight: t = (K/2) log2(chi2) - (chi2 - K) log2(e) / 2 - (K/2) log2(K)
-    float T0 = (float)(-0.5 * K * log2(K));
-    const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh * 0.99) : -INFINITY;       // the fp32 screen keeps a 1 % margin
+    // The classifier: t ~ log2 of the pair's weight = (K/2) log2(chi2 / K) - (chi2 - K) log2(e) / 2, in four fp32 instructions and no
+    // transcendental -- log2(chi2) is read off the float's bits (exponent + mantissa as a fraction: the piecewise-linear log2, at most
+    // 0.0861 low; centred, +-0.043), so  t = hk23 * float(bits) - 0.7213 * chi2 + T0c  with an error below 0.045 K / 2 + 1e-4.  The
+    // margins below (tmarg) cover it; nothing that reaches an output is computed from t.
+    auto t_consts = [](double Kd, float& hk23, float& T0c, float& tmarg) {
+        const double hk = 0.5 * Kd;
+        hk23 = (float)(hk / 8388608.0);
+        T0c = (float)((Kd > 0.0 ? -hk * log2(Kd) : 0.0) + Kd * 0.7213475204444817 + hk * (-127.0 + 0.043));
+        tmarg = (float)(0.5 + 0.045 * hk);
+    };
+    float hk23, T0c, tmarg;
+    t_consts(K, hk23, T0c, tmarg);
+    float tzero = K > 0.0 ? -INFINITY : T0c;                      // t of chi2 == 0 (power 0: weight 1)
+    const float lthr2 = (wt_thresh > 0.0) ? (float)log2(wt_thresh) : -INFINITY;
     // the drop bar: log2 of the share of the best weight below which a pair cannot matter to an fp64 sum over M of them
     // (2^-55 / M, and one more bit for the classifier's own error: |t - log2 w| < 1e-4 for every pair that could sit at the bar of an
     // object that stays here, see `ok`); never above the stacking threshold
     int mbits = 0;
     while (((int64_t)1 << mbits) < (int64_t)M) ++mbits;
-    const float ldrop = fminf(lthr2, -(float)(56 + mbits));
+    const float ldrop0 = fminf(lthr2, -(float)(55 + mbits));      // (minus the classifier's margin, per object: tmarg)
     const double thr_def = wt_thresh * (1.0 + 1e-3);              // above this a weight is stacked whatever the maximum turns out to be
     auto lnl_c2 = [&](double c2) {
         if constexpr (KRT) return (wpr == 0) ? fma(-0.5, c2, -lgq) : chi2_logpdf<true>(0.5 * K, c2, lgq, tb);      // (power 0: no x log x term)
@@ -233,7 +244,6 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
         else return hist_exactw<WP, decltype(small)::value>(c2, t);
     };
-    float halfk = 0.5f * (float)K;
     double lref = uniform_d(lnl_c2(K));                           // ln L at the mode: the reference of every weight
 
     for (int64_t rnd = 0; rnd < nrounds; ++rnd) {
@@ -260,8 +270,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             const bool dp = src.lp.dim_prior != 0;
             if (!dp) { wpr = 0; kok = true; }
             K = uniform_d((double)wpr);                                 // (wave-uniform: scalar registers)
-            T0 = (wpr > 0) ? uniform_f((float)(-0.5 * K * log2(K))) : 0.f;
-            halfk = uniform_f(0.5f * (float)K);
+            t_consts(K, hk23, T0c, tmarg);
+            hk23 = uniform_f(hk23); T0c = uniform_f(T0c); tmarg = uniform_f(tmarg);
+            tzero = wpr > 0 ? -INFINITY : T0c;
             lgq = uniform_d(dp ? src.lp.lgtab[nb] : 0.5 * ((double)nb * FZ_LN2PI + src.ov.slv[oi]));
             lref = uniform_d(lnl_c2(K));
         }
@@ -398,10 +409,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         for (int q = 0; q < MP; ++q)
 #pragma unroll
                             for (int o = 0; o < TW; ++o) {
-                                const float cf = (float)c2[q][o];
-                                const float l2 = __builtin_amdgcn_logf(cf);             // chi2 == 0: -inf; a negative screen value: nan
-                                const float df = (float)(c2[q][o] - K);                 // fp64 difference, then fp32
-                                tl[q][o] = fmaf(l2, halfk, fmaf(df, -0.72134752f, T0));   // -inf for chi2 == 0; nan only beyond fp32's range
+                                const float cf = (float)c2[q][o];                         // chi2 >= 0 (inf: t = -inf; nan: nan, settled and found weightless)
+                                tl[q][o] = fmaf((float)__float_as_int(cf), hk23, fmaf(cf, -0.72134752f, T0c));
+                                // chi2 == 0 (a training-set self match) has weight 0 for every power K > 0: its t must be -inf, not the -127 K / 2 the bit
+                                // trick gives -- a finite t would pass for the object's best weight when everything else lies far below it
+                                tl[q][o] = (cf != 0.f) ? tl[q][o] : tzero;
                                 if (TAIL) tl[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? tl[q][o] : -INFINITY;   // pad lanes: dropped whatever the bar
                             }
 #pragma unroll
@@ -428,11 +440,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                 for (int o = 0; o < TW; ++o) {
                                     const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
                                     hs.tmax[o] = mx;
-                                    hs.tthr[o] = mx + ldrop;
-                                    // 0.98 wt_thresh 2^mx in fp64 (mx may lie below fp32's exponent range): 2^frac by v_exp_f32, 2^int by v_ldexp_f64
-                                    const float fl = floorf(mx);
-                                    const double wb = (mx > -1000.f) ? __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(mx - fl), (int)fl) : 0.0;
-                                    hs.wamb[o] = uniform_d(wb * (wt_thresh * 0.98));
+                                    hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
+                                    // wt_thresh 2^(mx - margin) in fp64 (mx may lie below fp32's exponent range): 2^frac by v_exp_f32, 2^int by v_ldexp_f64
+                                    const float mlo = mx - tmarg - 0.03f, fl = floorf(mlo);
+                                    const double wb = (mx > -1000.f) ? __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(mlo - fl), (int)fl) : 0.0;
+                                    hs.wamb[o] = uniform_d(wb * wt_thresh);
                                 }
                             }
 #pragma unroll

@@ -15,7 +15,7 @@
 // query's sorted list (LDS, ordered by (distance, original index)) -- the neighbour table is the exact fp64
 // top-k, bit for bit, whatever the visiting order (tests/test_hip_knn.py
 // test_matrix_pipe_search_is_the_exact_search, tests/test_hip_fullsize.py at M = 1e5, K = 25, k = 20).
-// Around that: seeds from feature set 0, models and queries in Morton order with an outward scan from the
+// Around that: seeds from feature set 0, models in k-d order (tiles = leaves) and queries grouped by leaf with an outward scan from the
 // queries' own place, and tiles / groups of tiles skipped by bounding box (comments at k_knn_mfma).
 //
 // Bar.  u = 2^-24, Q = |q'|, P = max_p |p - c|, C = |c|.  Without rounding the product is
@@ -34,8 +34,7 @@ typedef float fz_f4 __attribute__((ext_vector_type(4)));
 
 #define FZ_KM_TILE 64                   // models per LDS tile
 #define FZ_KM_TFLOATS (FZ_KM_TILE * 8)  // 8 slots per model
-#define FZ_KM_TSTR 544                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi) + the box of its group of tiles
-#define FZ_KM_GT 8                      // tiles per group (aligned): a group whose box is out of reach is skipped at its first tile, unstaged
+#define FZ_KM_TSTR 544                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi) + 16 spare (the stride keeps the LDS-DMA chunking: 2176 B)
 
 // per-feature mean of one feature set (one block per set), in fp64
 static __global__ __launch_bounds__(256) void k_knn_center(const float* __restrict__ in, int64_t M, int F, float* __restrict__ cen) {
@@ -55,7 +54,7 @@ static __global__ __launch_bounds__(256) void k_knn_center(const float* __restri
 // B operands: [set][64-model block][half kb][lane][group g] floats -- lane l of the wave reads, for the
 // four 16-model groups of a 64-model step, slot kb*4 + (l >> 4) of model 16 g + (l & 15) as ONE 16-byte
 // LDS read.  Slots: p_f (f < F, the original float), 1 (slot F), beta (slot F+1), 0.  Pad models: beta = 1e30.
-// perm (may be null): position j of set t holds model perm[t][j] (the set's models in Morton order, see k_knn_mfma);
+// perm (may be null): position j of set t holds model perm[t][j] (the set's models in k-d order, fz_knn_host.inc);
 // with F <= 5 slot 7 is free and carries the model's ORIGINAL index as a float (exact below 2^24; its A-side
 // factor is 0), so that the admission path gets it from the tile.
 static __global__ __launch_bounds__(256) void k_knn_pack_mfma(const float* __restrict__ in, int64_t M, int F, int64_t Mp,
@@ -107,22 +106,6 @@ static __global__ __launch_bounds__(64) void k_knn_boxes(const float* __restrict
     }
 }
 
-// box of every aligned group of FZ_KM_GT tiles, copied behind each of its tiles' own box (so that whichever tile a scan
-// enters the group through carries it)
-static __global__ __launch_bounds__(64) void k_knn_gboxes(int64_t Mp, float* __restrict__ bmat) {
-    const int lane = threadIdx.x, t = blockIdx.y;
-    const int64_t ntl = Mp >> 6, g0 = (int64_t)blockIdx.x * FZ_KM_GT;
-    float* base = bmat + (size_t)t * ntl * FZ_KM_TSTR;
-    if (lane >= 16) return;
-    float v = lane < 8 ? INFINITY : -INFINITY;
-    for (int u = 0; u < FZ_KM_GT; ++u) {
-        if (g0 + u >= ntl) break;
-        const float b = base[(g0 + u) * FZ_KM_TSTR + 512 + lane];
-        v = lane < 8 ? fminf(v, b) : fmaxf(v, b);
-    }
-    for (int u = 0; u < FZ_KM_GT; ++u) if (g0 + u < ntl) base[(g0 + u) * FZ_KM_TSTR + 528 + lane] = v;
-}
-
 // second level of the skipping: boxes of at most 128 groups of 2^gsl consecutive tiles (k-d order: consecutive leaves are subtrees or
 // neighbouring subtrees), [set][128][lo 8 | hi 8].  A wave tests them all at once against its 16 queries' bars (k_knn_mfma: two
 // lane-parallel rounds) and keeps the result as a 128-bit mask in scalar registers; the scan then steps over unreachable groups
@@ -140,21 +123,6 @@ static __global__ __launch_bounds__(64) void k_knn_maskboxes(int64_t Mp, int M, 
     gbox[((size_t)t * 128 + g) * 16 + lane] = v;          // (no tile: lo = +inf, hi = -inf)
 }
 
-// 12-bit Morton prefix of a feature vector: features quantised to 10 bits inside the set's bounding box (lo, scale),
-// bits interleaved most significant first.  Used to order a set's models (host, at upload), to order the queries
-// (k_knn_qhist / k_knn_qscatter) and to find where a wave's queries sit among a set's models (k_knn_mfma).
-__host__ __device__ inline unsigned knn_prefix12(const double* v, const float* bnd, int F) {
-    unsigned qv[8];
-    for (int f = 0; f < F; ++f) {
-        float x = ((float)v[f] - bnd[f]) * bnd[8 + f];
-        x = x < 0.f ? 0.f : (x > 1023.f ? 1023.f : x);
-        qv[f] = (unsigned)x;
-    }
-    const int nb = 10 * F < 12 ? 10 * F : 12;
-    unsigned p = 0;
-    for (int n = 0; n < nb; ++n) p = (p << 1) | ((qv[n % F] >> (9 - n / F)) & 1u);
-    return p << (12 - nb);
-}
 // leaf (= 64-model tile) of a point in a set's implicit k-d tree (k-d order of the models, fz_knn_host.inc): the node over tiles [a, b)
 // splits at mid = a + (b - a) / 2 along feature sp[2 mid] at value sp[2 mid + 1] (float bits)
 __device__ inline int knn_kd_leaf(const double* v, const int* __restrict__ sp, int ntiles) {
@@ -167,19 +135,18 @@ __device__ inline int knn_kd_leaf(const double* v, const int* __restrict__ sp, i
     }
     return a;
 }
-// bucket of a query for the counting sort: its leaf in set 0's k-d tree (scaled into 4096 buckets), or its 12-bit Morton prefix
-__device__ inline unsigned knn_qbucket(const double* v, const float* bnd, int F, const int* __restrict__ sp, int kdn) {
-    if (kdn <= 0) return knn_prefix12(v, bnd, F);
+// bucket of a query for the counting sort: its leaf in set 0's k-d tree (scaled into 4096 buckets)
+__device__ inline unsigned knn_qbucket(const double* v, const int* __restrict__ sp, int kdn) {
     int sh = 0;
     while ((kdn >> sh) > 4096) ++sh;
     return (unsigned)(knn_kd_leaf(v, sp, kdn) >> sh);
 }
 // counting sort of the queries by prefix (the order inside a bucket is whatever the atomics give: every query's
 // result is independent of the wave that computes it)
-static __global__ void k_knn_qhist(const double* __restrict__ q, int64_t N, int F, const float* __restrict__ bnd, int* __restrict__ cnt,
+static __global__ void k_knn_qhist(const double* __restrict__ q, int64_t N, int F, int* __restrict__ cnt,
                                    const int* __restrict__ sp, int kdn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) atomicAdd(&cnt[knn_qbucket(q + i * F, bnd, F, sp, kdn)], 1);
+    if (i < N) atomicAdd(&cnt[knn_qbucket(q + i * F, sp, kdn)], 1);
 }
 static __global__ __launch_bounds__(1024) void k_knn_qscan(int* __restrict__ cnt) {       // exclusive scan of 4096 counts, one block
     __shared__ int part[1024];
@@ -192,10 +159,10 @@ static __global__ __launch_bounds__(1024) void k_knn_qscan(int* __restrict__ cnt
     int base = part[t] - s;
     for (int u = 0; u < 4; ++u) { cnt[4 * t + u] = base; base += v[u]; }
 }
-static __global__ void k_knn_qscatter(const double* __restrict__ q, int64_t N, int F, const float* __restrict__ bnd, int* __restrict__ off,
+static __global__ void k_knn_qscatter(const double* __restrict__ q, int64_t N, int F, int* __restrict__ off,
                                       int* __restrict__ qperm, const int* __restrict__ sp, int kdn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) qperm[atomicAdd(&off[knn_qbucket(q + i * F, bnd, F, sp, kdn)], 1)] = (int)i;
+    if (i < N) qperm[atomicAdd(&off[knn_qbucket(q + i * F, sp, kdn)], 1)] = (int)i;
 }
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -309,7 +276,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                                                          const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
                                                          int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
                                                          int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
-                                                         const int* __restrict__ qperm, const int* __restrict__ ktab, const float* __restrict__ kbnd, int kdorder,
+                                                         const int* __restrict__ qperm, const int* __restrict__ ktab,
                                                          const float* __restrict__ gbox, int gsl) {
     static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
     static_assert(KPL == 0 || KPL == 5 || KPL == 8, "register lists: k <= 20 or k <= 32");
@@ -335,7 +302,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
     if (lane < 16) qn[lane] = 0;
     // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
-    // qperm (may be null): the queries in Morton order -- the 16 queries of a wave are neighbours in feature space
+    // qperm (may be null): the queries grouped by their leaf in set 0's tree -- the 16 queries of a wave are neighbours in feature space
     const int64_t islot = i0 + row < N ? i0 + row : N - 1;
     const int64_t qi = qperm ? (int64_t)qperm[islot] : islot;       // this lane's row, as an index into q / idx
     for (int ff = sl; ff < 6; ff += 4) qs[wave][row][ff] = (ff < F) ? q[qi * F + ff] : 0.0;
@@ -467,7 +434,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     };
 
     const int ntiles = (M + TILE - 1) / TILE;
-    // Visiting order.  The set's models are stored in Morton order (upload) and the wave's queries are neighbours
+    // Visiting order.  The set's models are stored in k-d order (upload: depth-first leaves) and the wave's queries are neighbours
     // (qperm), so the tiles around the queries' own place hold most of their neighbours: start there and work outwards,
     // alternating sides.  The bar then drops to nearly its final value within the first few per cent of the models and
     // the rest of the scan admits little (benchmark data: 55-65 admissions per query instead of 87).  The lists are
@@ -511,12 +478,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     };
     bool need_mask = seed != nullptr;                    // seeded sets: the bars are near their final values from the start
     if (NWB == 1 && ktab) {
-        double qm[8];
-#pragma unroll
-        for (int f = 0; f < 6; ++f) qm[f] = qs[wave][8][f];
-        // k-d order: the leaf of the wave's middle query in THIS set's tree (11 dependent pairs of scalar loads at M = 1e5); Morton order: the prefix table
-        const int hm = kdorder ? knn_kd_leaf(&qs[wave][8][0], ktab + (size_t)tree * ntiles * 2, ntiles) :     // (the query straight from LDS: a dynamic index into registers would go to scratch)
-                                 ktab[(size_t)tree * 4096 + knn_prefix12(qm, kbnd + tree * 16, F)] / TILE;
+        // the leaf of the wave's middle query in THIS set's tree (11 dependent pairs of scalar loads at M = 1e5; the query straight from
+        // LDS: a dynamic index into registers would go to scratch)
+        const int hm = knn_kd_leaf(&qs[wave][8][0], ktab + (size_t)tree * ntiles * 2, ntiles);
         sc.nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); sc.nl = sc.nr - 1;
     }
     sc.fetch(bm, sl);
@@ -536,7 +500,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
             const int e = has ? __builtin_ctz(pm) : 0;
             pm &= pm - 1u;
             const int g = e >> 2, r = e & 3, R = 4 * sl + r;
-            const int jpos = jb + 16 * g + row;                      // position in the (Morton-ordered) set
+            const int jpos = jb + 16 * g + row;                      // position in the (k-d-ordered) set
             double qv[FL]; float pv[FL];                             // exact distance from the original query and features
 #pragma unroll
             for (int f = 0; f < FL; ++f) { qv[f] = qs[wave][R][f]; pv[f] = blk[(f >> 2) * 256 + ((f & 3) * 16 + row) * 4 + g]; }

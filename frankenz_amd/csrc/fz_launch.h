@@ -2,7 +2,6 @@
 #pragma once
 #include "fz_ctx.h"
 #include "fz_kernels.h"
-#include "fz_ol.h"
 #include "fz_nolist.h"
 #include "fz_hist.h"
 #include "fz_plane.h"
@@ -104,12 +103,11 @@ inline int fz_launch_plane_rows(fz_ctx* c, const double* plane, const fz::KdeVie
     // shapes: 5 120 entries (8 waves x 5 register pairs), 10 240 (8 x 10), 20 480 (16 x 10); a row must fill 80 % of its shape
     // (a 15 000-entry row on the 20 480 shape is slower than k_plane_fused: 2.56 vs 2.40 ms per 66 000 rows)
     int nw = 0, e2 = 0;
-    if (const char* e = getenv("FZ_PLANE_ROWS_CFG")) sscanf(e, "%d,%d", &nw, &e2);
-    else if (M <= 5120) { nw = 8; e2 = 5; }
+    if (M <= 5120) { nw = 8; e2 = 5; }
     else if (M <= 10240) { nw = 8; e2 = 10; }
     else { nw = 16; e2 = 10; }
     const int64_t capn = (int64_t)nw * 64 * 2 * e2;
-    if (M > capn || (!getenv("FZ_PLANE_ROWS_CFG") && M * 5 < capn * 4)) return 1;
+    if (M > capn || M * 5 < capn * 4) return 1;
     if (nw == 8 && e2 == 5) return fz_launch_plane_rows_g<8, 5>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
     if (nw == 8 && e2 == 10) return fz_launch_plane_rows_g<8, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
     if (nw == 16 && e2 == 10) return fz_launch_plane_rows_g<16, 10>(c, plane, kv, n, M, ko, lmap, levid, pdfs);
@@ -338,59 +336,6 @@ double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
     }
 }
 
-// list-free two-pass form for broad likelihoods (fz_nolist.h); +1 = not applicable / does not fit
-template <class SRC>
-int fz_launch_nolist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
-                     double* lmap, double* levid, double* pdfs) {
-    if constexpr (!fz_has_wspace<SRC>()) return 1;
-    else {
-        constexpr int NW = 16, SW = 4;
-        if (!fz_use_wspace(src) || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return 1;
-        auto k1 = fz::k_nl_max<SRC, NW>;
-        auto k2 = fz::k_nl_main<SRC, NW>;
-        const size_t lds = (size_t)NW * kv.acc_stride * 8;
-        {
-            hipFuncAttributes fa;
-            HIPCHK(hipFuncGetAttributes(&fa, (const void*)k2));
-            if (fa.sharedSizeBytes + lds > 160 * 1024) return 1;
-        }
-        HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FZCHK(c->d_nlmax.ensure((size_t)n * 8));
-        FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
-        HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
-        FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
-        HIPCHK(hipMemsetAsync(c->d_redo.p, 0, sizeof(int), c->stream));
-        // the sweep over handed-back objects keeps candidate lists: SW waves' worth
-        const size_t sweep_ws = (size_t)c->cu_count * SW * M * sizeof(fz::Cand);
-        if ((int64_t)sweep_ws > c->ws_limit || c->d_cand.ensure(sweep_ws) != 0) return 1;
-        HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
-        int b1 = 1, b2 = 1;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (const void*)k1, NW * 64, 0));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (const void*)k2, NW * 64, lds));
-        const int64_t g1 = std::min<int64_t>(((n + 1) / 2 + NW - 1) / NW, (int64_t)std::max(1, b1) * c->cu_count);
-        const int64_t g2 = std::min<int64_t>((n + NW - 1) / NW, (int64_t)std::max(1, b2) * c->cu_count);
-        Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
-        hipLaunchKernelGGL(k1, dim3((unsigned)g1), dim3(NW * 64), 0, c->stream, src, n, (int)M, c->omap, c->d_nlmax.as<double>());
-        hipLaunchKernelGGL(k2, dim3((unsigned)g2), dim3(NW * 64), lds, c->stream, src, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
-                           (int)M, ko->wt_thresh, ko->normalize, c->omap, c->d_nlmax.as<double>(), lmap, levid, pdfs, c->d_redo.as<int>());
-        {
-            auto sweep = fz::k_fused<SRC, 1, SW, false, true>;
-            constexpr size_t TDB2 = (size_t)SRC::template tile_doubles<SRC::template tile_len<SW>()>();
-            const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
-            hipFuncAttributes fa;
-            HIPCHK(hipFuncGetAttributes(&fa, (const void*)sweep));
-            if (fa.sharedSizeBytes + lds2 <= 160 * 1024) {
-                HIPCHK(hipFuncSetAttribute((const void*)sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>(c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, src,
-                                   c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
-                                   lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
-            }
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-}
-
 // single pass with in-kernel LDS histograms and no candidate lists (fz_hist.h); +1 = not applicable / does not fit.
 // exact: every weight in fp64 (the all-fp64 evidence, and the form for broad likelihoods)
 // OBJK / SWS: per-object band counts (fz_hist.h); the sweep over handed-back objects then runs on `sws`, the MASKED variant of
@@ -525,43 +470,6 @@ int fz_launch_hist_only(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const f
     return r;
 }
 
-// object-per-lane single pass (fz_ol.h); +1 = does not fit, caller takes the k_fused route
-template <class SRC, int OPL>
-int fz_launch_ol(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
-                 double* lmap, double* levid, double* pdfs) {
-    using namespace fz;
-    const int64_t W = (M + 31) / 32;
-    const int64_t per_block = 4 * 64 * OPL;
-    const int64_t nblk = (n + per_block - 1) / per_block;
-    const size_t mask_bytes = (size_t)(nblk * 4 * OPL) * W * 64 * 4;       // whole waves write whole rows
-    if ((int64_t)mask_bytes > c->ws_limit) return 1;
-    if (c->d_cand.ensure(mask_bytes) != 0) return 1;
-    FZCHK(c->d_olstats.ensure((size_t)n * sizeof(OlStats)));
-    FZCHK(c->d_kv.ensure(sizeof(KdeView)));
-    HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    constexpr int NWV = 8;
-    const size_t lds2 = (size_t)NWV * kv.acc_stride * 8 + (size_t)NWV * FZ_OL_TILE * 4 + (size_t)NWV * FZ_OL_SEG * 2;
-    if (lds2 > 160 * 1024) return 1;
-    auto k1 = k_ol<SRC, OPL>;
-    auto k2 = k_ol_pdf<SRC, NWV>;
-    HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    {
-        Timer t(c, &c->tm.ms_fused, &c->tm.n_fused);
-        hipLaunchKernelGGL(k1, dim3((unsigned)nblk), dim3(256), 0, c->stream, src, n, (int)M, ko->wt_thresh,
-                           c->d_cand.as<uint32_t>(), c->d_olstats.as<OlStats>());
-    }
-    HIPCHK(hipGetLastError());
-    {
-        Timer t(c, &c->tm.ms_kde, &c->tm.n_kde);
-        hipLaunchKernelGGL(k2, dim3((unsigned)((n + NWV - 1) / NWV)), dim3(NWV * 64), lds2, c->stream, src, c->d_kv.as<KdeView>(),
-                           kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<uint32_t>(),
-                           c->d_olstats.as<OlStats>(), lmap, levid, pdfs);
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 // fit_predict on a prepared chunk: single pass when possible, else two passes
 template <class SRC>
 int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap,
@@ -592,24 +500,6 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             }
             r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact || broad);
             if (r <= 0) { c->last_form = (exact || broad || SRC::LMODE == 2) ? ((exact || SRC::LMODE == 2) ? "k_hist<exact>" : "k_hist<exact> (broad likelihoods)") : "k_hist<screen>"; return r; }
-        }
-        // broad likelihoods run without candidate lists (fz_nolist.h: two passes over the models, nothing in HBM).  The
-        // share of pairs within the weight threshold is measured on 256 sampled objects of the launch; FZ_NOLIST=1 / 0
-        // forces / forbids the form (launches below 16 384 objects keep the lists unless forced)
-        {
-            const char* e = getenv("FZ_NOLIST");
-            int want = e ? atoi(e) : -1;
-            if (want < 0 && n >= 16384) want = (share > -2.0 ? share : fz_nolist_probe<SRC>(c, src, kv, n, M, ko)) > 0.22 ? 1 : 0;
-            if (want == 1) {
-                r = fz_launch_nolist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                if (r <= 0) { c->last_form = "k_nl_max + k_nl_main"; return r; }
-            }
-        }
-        if constexpr (SRC::WPOW == 3 && SRC::NB == 5) {
-            if (fz_use_wspace(src) && getenv("FZ_OL") && !c->omap) {
-                r = fz_launch_ol<SRC, 2>(c, src, kv, n, M, ko, lmap, levid, pdfs);
-                if (r <= 0) return r;
-            }
         }
         if constexpr (SRC::NB > 16) {
             // wide records (17-32 bands): one object per wave keeps the kernel inside the register file

@@ -287,3 +287,38 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
             else:
                 np.testing.assert_array_equal(np.sort(d2[got[got < M]]), np.sort(d2[want[want < M]]))
                 assert (got == M).sum() == (want == M).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('switch', ['FZ_KNN_NOBOX', 'FZ_KNN_NOSEED', 'FZ_KNN_NOSORT', 'FZ_KNN_SERIAL', 'FZ_KNN_NOMFMA'])
+def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch):
+    """The diagnostic switches of the search -- no tile / group skipping, no seeds from feature set 0, models in storage order
+    instead of k-d order (NOSORT is read at upload), wave-serial list insertion, the vector-ALU search instead of the matrix
+    pipe -- change how the table is found, never the table: ordered by (distance, model index) it is the all-fp64 scan's, bit
+    for bit, on clumpy data with exact duplicates (ties at the k-th place) and enough models for 3 tile groups."""
+    from frankenz_amd.engine import get_engine
+    rs = np.random.RandomState(2718)
+    K, M, F, N, k = 3, 9000, 5, 333, 20
+    cen = rs.normal(22.0, 2.0, size=(40, F))
+    base = cen[rs.randint(0, 40, M)] + rs.normal(0, 0.05, size=(M, F))
+    base[4000:4400] = base[:400]                                         # exact duplicates
+    feats = np.stack([base + rs.normal(0, 0.02, size=(M, F)) for _ in range(K)]).astype(np.float32)
+    feats[1] = feats[0]                                                   # one set identical to set 0: its seeds are its answer
+    q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
+    q[:20] = feats[0][:20].astype(np.float64)                             # distance exactly 0 to two models each
+    eng = get_engine()
+    eng.upload_models(np.ones((M, F)), np.zeros((M, F)), np.ones((M, F)))
+
+    def search(env):
+        with monkeypatch.context() as mp:
+            for e in env:
+                mp.setenv(e, '1')
+            eng._trees_key = None                                         # (the upload cache does not know about the environment)
+            eng.knn_upload_trees(feats)
+            idx = np.empty((N, K * k), dtype=np.int64)
+            eng.knn_query(np.ascontiguousarray(q), k, np.inf, idx)
+        return idx
+    want = search(['FZ_KNN_FP64'])
+    np.testing.assert_array_equal(search([]), want)
+    np.testing.assert_array_equal(search([switch]), want)
+    eng._trees_key = None

@@ -374,30 +374,6 @@ def test_more_than_32_bands_is_refused():
         BruteForce(Y, 0.1 * Y, np.ones_like(Y)).fit(Y[:2].copy(), Y[:2].copy(), np.ones((2, 33)), verbose=False)
 
 
-@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}])
-def test_object_per_lane_path_matches(kw, monkeypatch):
-    """FZ_OL=1 routes the unmasked 5-band chi2^(3/2) likelihoods through the object-per-lane
-    kernels (fz_ol.h): same PDFs / lmap / levid as the default path and as the oracle,
-    including self matches (chi2 == 0) and more objects than one wave holds."""
-    from frankenz_amd import BruteForce
-    d, od = dicts()
-    rs = np.random.RandomState(77)
-    M, N, B = 1500, 300, 5
-    Y = rs.lognormal(1., 1., size=(M, B)) * 3; Ye = 0.05 * Y; Ym = np.ones((M, B))
-    X = Y[rs.choice(M, N)] + SDSS5 * rs.randn(N, B); Xe = np.tile(SDSS5, (N, 1)); Xm = np.ones((N, B))
-    X[:20] = Y[:20]; Xe[:20] = Ye[:20]                     # exact self matches
-    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
-    run = lambda: BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
-                                                    return_gof=True, save_fits=False, verbose=False)
-    p0, (lm0, le0) = run()
-    monkeypatch.setenv('FZ_OL', '1')
-    p1, (lm1, le1) = run()
-    monkeypatch.delenv('FZ_OL')
-    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-12); close(le1, le0, **EVID)
-    rp, rlm, rle = fo.bruteforce_fit_predict(X[:60].copy(), Xe[:60].copy(), Xm[:60].copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
-    close(p1[:60], rp, rtol=1e-8, atol=1e-14); close(lm1[:60], rlm); close(le1[:60], rle, **EVID)
-
-
 @pytest.mark.parametrize('N,M', [(1, 1), (3, 2), (5, 63), (2, 64), (4, 256), (3, 257), (0, 10)])
 def test_tiny_and_boundary_shapes(N, M):
     """one object / one model, model counts around the wave (64) and tile (256) sizes, and an
@@ -467,7 +443,7 @@ def test_band_constant_model_errors_take_the_hoisted_path(kw, errs, monkeypatch)
 @pytest.mark.parametrize('env', [{'FZ_HIST': '0', 'FZ_FUSED_CFG': '4,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,8'}, {'FZ_HIST': '0', 'FZ_FUSED_CFG': '2,16'},
                                  {'FZ_HIST': '0', 'FZ_FUSED_CFG': '1,4'}, {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1'}, {'FZ_CHUNK': '5000'},
                                  {'FZ_HIST': '0', 'FZ_NO_WSPACE': '1', 'FZ_FUSED_CFG': '2,16'}, {'FZ_HIST': '0'},
-                                 {'FZ_HIST_CFG': '2,8'}, {'FZ_HIST_NOSCRB': '1'}, {'FZ_NOLIST': '1'}, {'FZ_HIST': '0', 'FZ_NOLIST': '1'},
+                                 {'FZ_NOLIST': '1'}, {'FZ_EXACT_EVIDENCE': '1'},
                                  {'FZ_HIST_AMBCAP': '3'}, {'FZ_HIST_AMBCAP': '3', 'FZ_NOLIST': '1'}])      # ambiguous lists of 3 entries: (nearly) every object overflows and is re-run by the exact sweep
 def test_tuning_switches_do_not_change_results(env, monkeypatch):
     """every launch geometry / kernel body / chunking reachable through the diagnostic
@@ -811,8 +787,8 @@ def test_class_sorted_stack_of_many_kernel_widths(kw, N, monkeypatch):
 @pytest.mark.parametrize('force', [None, '1'])
 def test_list_free_form_for_broad_likelihoods(kw, force, monkeypatch):
     """faint objects (most models within wt_thresh of the best): the launcher measures the share of pairs within the
-    threshold on a sample and runs the list-free two-pass form (fz_nolist.h) -- same PDFs / lmap / evidence as the
-    candidate-list form (FZ_NOLIST=0) and as the oracle; forced (FZ_NOLIST=1) on bright objects too, where a handful
+    threshold on a sample and runs the form of k_hist that weighs every pair directly instead of classifying it first -- same
+    PDFs / lmap / evidence as the classifier form (FZ_NOLIST=0) and as the oracle; forced (FZ_NOLIST=1) on bright objects too, where a handful
     of models carry the whole posterior, a training-set self match (chi2 == 0) sits among the models and one object
     matches nothing (every chi2 far above the mode)."""
     from frankenz_amd import BruteForce
