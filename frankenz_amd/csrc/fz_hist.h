@@ -155,7 +155,7 @@ struct HistState {
     double wmx[TW];          // per lane: largest exact weight among the settled pairs (ln-max = ln L(mode) + ln of it)
     float tmax[TW];          // per lane: largest log2 weight seen (the classifier's fp32 estimate)
     float tthr[TW];          // wave-uniform: pairs with log2 w at or below this are dropped
-    double wamb[TW];         // wave-uniform: a settled weight above this (0.98 wt_thresh x the best seen) that is not stacked at once waits in the ambiguous list
+    double wamb[TW];         // wave-uniform: a settled weight above this (0.999 wt_thresh x the best settled so far) that is not stacked at once waits in the ambiguous list
     int pend[TW];            // wave-uniform: entries waiting in the object's candidate buffer
     int namb[TW];            // wave-uniform: entries in the ambiguous list
     int tick, next;
@@ -441,10 +441,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                     const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
                                     hs.tmax[o] = mx;
                                     hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
-                                    // wt_thresh 2^(mx - margin) in fp64 (mx may lie below fp32's exponent range): 2^frac by v_exp_f32, 2^int by v_ldexp_f64
-                                    const float mlo = mx - tmarg - 0.03f, fl = floorf(mlo);
-                                    const double wb = (mx > -1000.f) ? __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(mlo - fl), (int)fl) : 0.0;
-                                    hs.wamb[o] = uniform_d(wb * wt_thresh);
+                                    // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
+                                    // what still waits in the buffer only raises it)
+                                    hs.wamb[o] = uniform_d(wave_max(hs.wmx[o]) * (wt_thresh * 0.999));
                                 }
                             }
 #pragma unroll

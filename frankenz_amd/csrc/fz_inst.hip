@@ -304,7 +304,8 @@ int FZ_NAME(fz_knnsubset_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_
     FZCHK(c->d_kv.ensure(sizeof(KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const size_t per_wave = (size_t)kv.acc_stride + FZ_KNN_WMAX + (FZ_KNN_WMAX + 2 * FZ_KNN_HASH) / 2;
+    const int wcap = fz_knn_wcap(W);
+    const size_t per_wave = (size_t)kv.acc_stride + wcap + (size_t)(wcap + 4 * wcap) / 2;      // row | lnl | list, hash keys, hash positions (fz_knn.h)
     int wpb = 4;
     while (wpb > 1 && per_wave * 8 * wpb > 80 * 1024) wpb >>= 1;
     const size_t lds = per_wave * 8 * wpb;

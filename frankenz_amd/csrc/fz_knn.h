@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void k_knn_query32(const float* __restrict__ f
 // ---------------------------------------------------------------------------
 // subset likelihood + PDF, one object per wave
 // ---------------------------------------------------------------------------
-#define FZ_KNN_HASH 1024          // open-addressing table slots (>= 2 * W)
-#define FZ_KNN_WMAX 512           // largest K*k handled
+// capacities per launch: wcap = K*k rounded up to a power of two (>= 64), hash table of 2 wcap slots (open addressing)
+#define FZ_KNN_WMAX 4096          // largest K*k handled (k <= 64 per set, any K up to 64: the reference takes any; knn.py:190-193)
+__host__ __device__ inline int fz_knn_wcap(int W) { int c = 64; while (c < W) c <<= 1; return c; }
 
 struct KnnOut {                    // padded outputs of knn.py:812-821 (any may be NULL)
     int64_t* neighbors;            // (N,W) -99 padded
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
                                                     int64_t N, int M, const int64_t* __restrict__ idx, int W,
                                                     int free_scale, double wt_thresh, int normalize, KnnOut out,
                                                     int* __restrict__ errflag) {
-    // LDS per wave (doubles): row[acc_stride] | lnl[WMAX] | then ints: list[WMAX], key[HASH], pos[HASH]
+    // LDS per wave (doubles): row[acc_stride] | lnl[wcap] | then ints: list[wcap], key[2 wcap], pos[2 wcap]
     extern __shared__ double smem[];
     PH ph = ph_;
     ph.tb = global_tabs();
@@ -220,16 +221,17 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= N) return;
-    const size_t per_wave = (size_t)acc_stride + FZ_KNN_WMAX + (FZ_KNN_WMAX + 2 * FZ_KNN_HASH) / 2;
+    const int wcap = fz_knn_wcap(W), hcap = 2 * wcap, hshift = 32 - (31 - __builtin_clz(hcap));
+    const size_t per_wave = (size_t)acc_stride + wcap + (size_t)(wcap + 2 * hcap) / 2;
     double* row = smem + wave * per_wave;
     double* lnls = row + acc_stride;
-    int* list = reinterpret_cast<int*>(lnls + FZ_KNN_WMAX);
-    int* hkey = list + FZ_KNN_WMAX;
-    int* hpos = hkey + FZ_KNN_HASH;
+    int* list = reinterpret_cast<int*>(lnls + wcap);
+    int* hkey = list + wcap;
+    int* hpos = hkey + hcap;
     const KdeView kv = *kvp;
 
     // ---- pandas.unique: keep first appearances, in order (knn.py:840) ----
-    for (int s = lane; s < FZ_KNN_HASH; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
+    for (int s = lane; s < hcap; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
     const int64_t* myrow = idx + i * W;
     bool bad = false;
     for (int p0 = 0; p0 < W; p0 += 64) {
@@ -238,11 +240,11 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
             const long long v = myrow[p];
             if (v < 0 || v >= M) bad = true;          // KDTree's "missing" index: models[M] raises in the reference
             const int key = (int)v;
-            unsigned h = ((unsigned)key * 2654435761u) >> 22;          // 10 bits
+            unsigned h = ((unsigned)key * 2654435761u) >> hshift;          // log2(hcap) bits
             while (true) {
                 const int prev = atomicCAS(&hkey[h], -1, key);
                 if (prev == -1 || prev == key) break;
-                h = (h + 1) & (FZ_KNN_HASH - 1);
+                h = (h + 1) & (hcap - 1);
             }
             atomicMin(&hpos[h], p);
         }
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
         bool first = false; int key = 0;
         if (p < W) {
             key = (int)myrow[p];
-            unsigned h = ((unsigned)key * 2654435761u) >> 22;
-            while (hkey[h] != key) h = (h + 1) & (FZ_KNN_HASH - 1);
+            unsigned h = ((unsigned)key * 2654435761u) >> hshift;
+            while (hkey[h] != key) h = (h + 1) & (hcap - 1);
             first = (hpos[h] == p);
         }
         const unsigned long long mask = __ballot(first);
@@ -323,10 +325,11 @@ static __global__ __launch_bounds__(256) void k_knn_dedup(int64_t N, int M, cons
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= N) return;
-    int* list = reinterpret_cast<int*>(smem) + wave * (FZ_KNN_WMAX + 2 * FZ_KNN_HASH);
-    int* hkey = list + FZ_KNN_WMAX;
-    int* hpos = hkey + FZ_KNN_HASH;
-    for (int s = lane; s < FZ_KNN_HASH; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
+    const int wcap = fz_knn_wcap(W), hcap = 2 * wcap, hshift = 32 - (31 - __builtin_clz(hcap));
+    int* list = reinterpret_cast<int*>(smem) + (size_t)wave * (wcap + 2 * hcap);
+    int* hkey = list + wcap;
+    int* hpos = hkey + hcap;
+    for (int s = lane; s < hcap; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
     const int64_t* myrow = idx + i * W;
     bool bad = false;
     for (int p0 = 0; p0 < W; p0 += 64) {
@@ -335,11 +338,11 @@ static __global__ __launch_bounds__(256) void k_knn_dedup(int64_t N, int M, cons
             const long long v = myrow[p];
             if (v < 0 || v >= M) bad = true;
             const int key = (int)v;
-            unsigned h = ((unsigned)key * 2654435761u) >> 22;
+            unsigned h = ((unsigned)key * 2654435761u) >> hshift;
             while (true) {
                 const int prev = atomicCAS(&hkey[h], -1, key);
                 if (prev == -1 || prev == key) break;
-                h = (h + 1) & (FZ_KNN_HASH - 1);
+                h = (h + 1) & (hcap - 1);
             }
             atomicMin(&hpos[h], p);
         }
@@ -351,8 +354,8 @@ static __global__ __launch_bounds__(256) void k_knn_dedup(int64_t N, int M, cons
         bool first = false; int key = 0;
         if (p < W) {
             key = (int)myrow[p];
-            unsigned h = ((unsigned)key * 2654435761u) >> 22;
-            while (hkey[h] != key) h = (h + 1) & (FZ_KNN_HASH - 1);
+            unsigned h = ((unsigned)key * 2654435761u) >> hshift;
+            while (hkey[h] != key) h = (h + 1) & (hcap - 1);
             first = (hpos[h] == p);
         }
         const unsigned long long mask = __ballot(first);

@@ -187,8 +187,8 @@ class NearestNeighbors():
     def _search_setup(self, k, eps, lp_norm, distance_upper_bound):
         if lp_norm not in (1, 2, np.inf):
             raise NotImplementedError("Minkowski norms 1, 2 and inf are implemented on the GPU (got %r)" % (lp_norm,))
-        if k > 64 or self.K * k > 512:
-            raise NotImplementedError("k <= 64 and K*k <= 512 are required (got k=%d, K=%d)" % (k, self.K))
+        if k > 64 or self.K * k > 4096:
+            raise NotImplementedError("k <= 64 and K*k <= 4096 are required (got k=%d, K=%d)" % (k, self.K))
         self.k = k
         self.eps = eps              # the search is exact; any eps >= 0 is honoured
         self.lp_norm = lp_norm

@@ -322,3 +322,34 @@ def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch
     np.testing.assert_array_equal(search([]), want)
     np.testing.assert_array_equal(search([switch]), want)
     eng._trees_key = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,k,mode', [(12, 50, 'B'), (33, 64, 'A'), (12, 50, 'C')])
+def test_knn_more_than_512_neighbours_per_object(K, k, mode):
+    """knn.py:190-193 takes any k and K: K k = 600 and 2 112 neighbour slots per object (round 3 stopped at 512) -- the subset
+    kernel's de-dup table and lists are sized per launch -- against the oracle: neighbour lists in first-appearance order, padded
+    fit rows, PDFs; mode C goes through the de-dup kernel + the fixed point on the subset."""
+    from frankenz_amd import NearestNeighbors
+    d, od = dicts()
+    rs = np.random.RandomState(K * 100 + k)
+    M, N, B = 2500, 24, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 20; Ye = Y * rs.uniform(0.01, 0.03, size=(M, B)); Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] * rs.choice([0.5, 1.0], N)[:, None] + SDSS_SIGMA * rs.randn(N, B)
+    Xe = np.tile(SDSS_SIGMA, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.04)
+    lk = {'A': {}, 'B': {'free_scale': True, 'ignore_model_err': True}, 'C': {'free_scale': True}}[mode]
+    nn = NearestNeighbors(Y, Ye, Ym, K=K, feature_map='identity', rstate=np.random.RandomState(5), verbose=False)
+    p, (lm, le) = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=k, label_dict=d,
+                                 lprob_kwargs=lk, return_gof=True, verbose=False)
+    assert nn.neighbors.shape == (N, K * k)
+    feats = fo.knn_train(Y, Ye, K, 'identity', np.random.RandomState(5))
+    q = fo.knn_query_features(X, Xe, 'identity', np.random.RandomState(6))
+    tab = fo.knn_neighbors_exact(feats, q, k)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, tab, z, ze, label_dict=od, **lk)
+    np.testing.assert_array_equal(nn.Nneighbors, rnn)
+    np.testing.assert_array_equal(nn.neighbors, rn)
+    np.testing.assert_allclose(nn.fit_lnprob, rlnp, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(p, rp, rtol=1e-7, atol=1e-13)
+    np.testing.assert_allclose(le, rle, rtol=1e-9)
+    np.testing.assert_allclose(lm, rlm, rtol=1e-9)

@@ -2,7 +2,7 @@
 # full regression of a build: every GPU test, smoke, the default bench line, k-NN line; PMC=1 adds the counter passes
 export TMPDIR=/tmp
 O=gpurun_out/${OUT:-r4full}; mkdir -p $O
-python -m pytest tests -m gpu -q -x > $O/gputest.log 2>&1; echo "pytest rc=$?"; tail -12 $O/gputest.log
+PYTHONUNBUFFERED=1 timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/gputest.log 2>&1; echo "pytest rc=$?"; tail -12 $O/gputest.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python3 bench.py --steps 5 --warmup 2 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 python3 -c "
