@@ -173,8 +173,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
         if (want_lnl_only && !sub.nbr && !getenv("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
         // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
-        const size_t lds = (size_t)M * 8;
-        auto launch = [&](auto kern, int T, const int* list, int64_t nobj) -> int {
+        auto launch = [&](auto kern, int T, size_t lds, const int* list, int64_t nobj) -> int {
             HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int bpc = 1;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, T, lds));
@@ -186,11 +185,12 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
         auto run = [&](auto fastc, const int* list, int64_t nobj) -> int {
             constexpr bool F = decltype(fastc)::value;
             using MCT = ModeC<BT, MASKED>;
-            if (M <= 1024) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, list, nobj); }
-            if (M <= 4096) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, list, nobj); }
-            if (M <= 768 * 14) { c->mc_info[3] = 768; return launch(k_modec_persist<MCT, F, 768, 14>, 768, list, nobj); }
+            const size_t lds = (size_t)M * 8;                    // the previous scale of every model
+            if (M <= 1024) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, lds, list, nobj); }
+            if (M <= 4096) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, lds, list, nobj); }
+            if (M <= 768 * 14) { c->mc_info[3] = 768; return launch(k_modec_persist<MCT, F, 768, 14>, 768, lds, list, nobj); }
             c->mc_info[3] = 512;
-            return launch(k_modec_persist<MCT, F, 512, 32>, 512, list, nobj);
+            return launch(k_modec_persist<MCT, F, 512, 32>, 512, lds, list, nobj);
         };
         if (fast) FZCHK(run(std::true_type{}, nullptr, n)); else FZCHK(run(std::false_type{}, nullptr, n));
         int res[3] = {0, 0, 0};                              // status, slowest object's iterations, ambiguous objects

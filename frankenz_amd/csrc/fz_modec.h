@@ -68,6 +68,36 @@ struct ModeC {
 #pragma unroll
         for (int q = 0; q < REC_W / 2; ++q) { const double2 w = rp[q]; rec[2 * q] = w.x; rec[2 * q + 1] = w.y; }
     }
+    // the FAST solve on a record already in registers (fluxes | squared errors), see solve<true>
+    __device__ __forceinline__ void solve_rec(int64_t i, const double (&rec)[REC_W], double sprev, double& s, double& lnl,
+                                              double& chi2, double& shape, const double2* lt) const {
+        double rv[BT], y[BT], x[BT];
+        double inter = 0.0; shape = 0.0;
+        double vprod = 1.0; int vexp = 0;
+        const double s2 = sprev * sprev;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            y[b] = rec[b];
+            x[b] = ov.x[i * BT + b];
+            const double var = fma(s2, rec[BT + b], ov.v[i * BT + b]);   // xe^2 + s^2 ye^2
+            rv[b] = rcp_nr<2>(var);
+            const double yr = y[b] * rv[b];
+            inter = fma(yr, x[b], inter);
+            shape = fma(yr, y[b], shape);
+            int e; vprod *= frexp(var, &e); vexp += e;
+        }
+        s = inter * rcp_nr<2>(shape);
+        chi2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const double d = fma(-s, y[b], x[b]);
+            chi2 = fma(d * d, rv[b], chi2);
+        }
+        FastTabs tl = global_tabs();
+        if (lt) tl.logt = lt;
+        const double slog = log_pos(vprod, tl) + (double)vexp * FZ_LN2;
+        lnl = -0.5 * chi2 - 0.5 * ((double)nband * FZ_LN2PI + slog);
+    }
     // lt: the 2 KB log table in LDS (k_modec_persist), or nullptr: the global copy
     template <bool FAST = false>
     __device__ __forceinline__ void solve(int64_t i, int64_t j, double sprev, double& s, double& lnl,
@@ -75,38 +105,12 @@ struct ModeC {
         if constexpr (FAST && !MASKED) {
             if (sub.nbr) j = sub.nbr[i * sub.W + j];
             ndim = nband;
-            double rv[BT], y[BT], x[BT];
-            double inter = 0.0; shape = 0.0;
-            double vprod = 1.0; int vexp = 0;
             // the model's record (fluxes, squared errors: 2 BT doubles in one 16-byte-aligned row of the array-of-records copy) in
             // BT 16-byte loads instead of 2 BT 8-byte ones from the band-major arrays: the record is re-read from L2 on every
             // iteration (it does not fit registers beside the other models of the thread), half the load instructions
-            constexpr int RW0 = REC_W;
-            double rec[RW0];
+            double rec[REC_W];
             load_rec(j, rec);
-            const double s2 = sprev * sprev;
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                y[b] = rec[b];
-                x[b] = ov.x[i * BT + b];
-                const double var = fma(s2, rec[BT + b], ov.v[i * BT + b]);   // xe^2 + s^2 ye^2
-                rv[b] = rcp_nr<2>(var);
-                const double yr = y[b] * rv[b];
-                inter = fma(yr, x[b], inter);
-                shape = fma(yr, y[b], shape);
-                int e; vprod *= frexp(var, &e); vexp += e;
-            }
-            s = inter * rcp_nr<2>(shape);
-            chi2 = 0.0;
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                const double d = fma(-s, y[b], x[b]);
-                chi2 = fma(d * d, rv[b], chi2);
-            }
-            FastTabs tl = global_tabs();
-            if (lt) tl.logt = lt;
-            const double slog = log_pos(vprod, tl) + (double)vexp * FZ_LN2;
-            lnl = -0.5 * chi2 - 0.5 * ((double)ndim * FZ_LN2PI + slog);
+            solve_rec(i, rec, sprev, s, lnl, chi2, shape, lt);
             return;
         }
         if (sub.nbr) j = sub.nbr[i * sub.W + j];
@@ -293,6 +297,11 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
     }
 }
 
+// (Round 4 tried the records STREAMED through two LDS buffers by LDS-DMA, tile m + 1 landing while tile m is solved, the previous
+//  scales moved from LDS to the state plane: 53.4 ms against 39.5 ms for this kernel on 2e4 x 1e4.  Twelve waves that meet at a
+//  barrier per tile hide less latency than twelve independent waves, and the bytes are the same: 0.96 MB of records per object and
+//  pass, 19 TB/s of L2 -> CU traffic over the launch, about half of what the eight L2s deliver -- the kernel sits between the
+//  L2 and the vector ALU, and only fewer bytes per pair-iteration (records that stay on chip) would move it.)
 static __global__ void k_modec_check(ModeCState st, int64_t Nc, double ltol, int iter) {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= Nc || (st.ncur && slot >= *st.ncur)) return;

@@ -9,8 +9,9 @@
 export TMPDIR=/tmp
 export FZ_BENCH_NO_EXTRA=1
 NOBJ=262144; STEPS=3
-while getopts "n:s:t:" o; do case $o in n) NOBJ=$OPTARG;; s) STEPS=$OPTARG;; t) TESTS=$OPTARG;; esac; done
-shift $((OPTIND - 1))
+while [[ $1 == -n || $1 == -s || $1 == -t ]]; do
+  case $1 in -n) NOBJ=$2;; -s) STEPS=$2;; -t) TESTS=$2;; esac; shift 2
+done
 mkdir -p gpurun_out
 if [ -n "$TESTS" ]; then python -m pytest tests -m gpu -x -q -k "$TESTS" 2>&1 | tail -3; fi
 for cfg in "$@"; do
