@@ -227,10 +227,12 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
 
 
 def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_label_errs, gather='pdfs',
-                        group=None, rstate=None, chunks=4, **kwargs):
+                        group=None, rstate=None, chunks=4, rounds_on_one_rank=False, **kwargs):
     """``fitter.fit_predict`` (BruteForce or NearestNeighbors) on this rank's block of objects.
     (``prepared=``: a handle from ``fitter.prepare_fit_predict(...)`` with the same labels and options -- the overlapped
-    BruteForce path then skips the uploads / content checks of models, dictionary and labels.)
+    path then skips the uploads / content checks of models, dictionary and labels.  ``rounds_on_one_rank=True``: take the
+    overlapped path -- rounds, stream contract, in-place collective -- in a one-rank group too (a test of the whole call form
+    through RCCL on a one-GPU box; with one rank the "gather" moves nothing).)
 
     Returns ``(pdfs, (lmap, levid))``: the FULL arrays when ``gather='pdfs'``; the local
     block when ``gather`` is ``None``; ``(stack, (lmap_local, levid_local))`` with the
@@ -243,7 +245,7 @@ def sharded_fit_predict(fitter, data, data_err, data_mask, model_labels, model_l
     n = len(data)
     # the reference's default is save_fits=True (bruteforce.py:374-378, knn.py:560-563): only an EXPLICIT save_fits=False takes the
     # device-resident path, which has no fit_* arrays to fill
-    if (gather == 'pdfs' and dist is not None and world > 1 and chunks
+    if (gather == 'pdfs' and dist is not None and (world > 1 or rounds_on_one_rank) and chunks
             and kwargs.get('lprob_func') is None and kwargs.get('save_fits', True) is False
             and (_gpu_ok() or getattr(fitter, 'accepts_tensors', False))):
         # built-in likelihood: device-resident, the gather overlapped with the compute (BruteForce and NearestNeighbors alike)

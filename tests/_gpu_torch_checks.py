@@ -129,7 +129,53 @@ def check_prepared_handle_survives_other_fitters():
     print("PREPARED_HANDLE_OK")
 
 
+def check_overlapped_rounds_through_rccl_on_one_rank():
+    """sharded._overlapped end to end with backend nccl (= RCCL) in a one-rank group: block-cyclic rounds, the stream contract,
+    async in-place all_gather_into_tensor per round, one fence -- for BruteForce and for NearestNeighbors -- must return what the
+    plain calls return (with one rank the collective moves nothing, but every call of the N > 1 path is made)."""
+    import torch
+    import torch.distributed as dist
+    from frankenz_amd import BruteForce, NearestNeighbors, PDFDict, sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dev = torch.device('cuda', 0)
+    pd = PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(30011, 2500, 15)
+    X[3, 1] = np.nan
+    bf = BruteForce(Y, Ye, Ym, device=0)
+    p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=pd, save_fits=False, return_gof=True, verbose=False)
+    dX, dXe, dXm = (torch.from_numpy(a.copy()).to(dev) for a in (X, Xe, Xm))
+    for chunks in (1, 4, 7):
+        q, (qm, qe) = sharded.sharded_fit_predict(bf, dX.clone(), dXe.clone(), dXm.clone(), z, ze, gather='pdfs', chunks=chunks,
+                                                  label_dict=pd, save_fits=False, rounds_on_one_rank=True)
+        assert sharded.last_stats['world'] == 1 and sharded.last_stats['chunks'] == chunks
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(q.cpu().numpy(), p, rtol=1e-12, atol=1e-16, equal_nan=True)
+        np.testing.assert_array_equal(qm.cpu().numpy(), lm)
+        np.testing.assert_allclose(qe.cpu().numpy(), le, rtol=1e-12, equal_nan=True)
+    # NumPy in, NumPy out (the caller's arrays get the in-place clean)
+    Xc = X.copy()
+    q, (qm, qe) = sharded.sharded_fit_predict(bf, Xc, Xe.copy(), Xm.copy(), z, ze, gather='pdfs', chunks=3, label_dict=pd,
+                                              save_fits=False, rounds_on_one_rank=True)
+    assert np.isfinite(Xc).all()
+    np.testing.assert_allclose(q, p, rtol=1e-12, atol=1e-16, equal_nan=True)
+    # k-NN
+    Y2 = Y * 3; Ye2 = 0.05 * Y2
+    X2 = Y2[np.random.RandomState(4).choice(len(Y2), 6001)] + SIG * np.random.RandomState(5).randn(6001, 5); Xe2 = np.tile(SIG, (6001, 1)); Xm2 = np.ones((6001, 5))
+    nn = NearestNeighbors(Y2, Ye2, Ym, K=7, feature_map='luptitude', fmap_kwargs=dict(skynoise=SIG, zeropoints=10 ** (0.4 * 23.9)),
+                          rstate=np.random.RandomState(1), verbose=False, device=0)
+    p2, (lm2, le2) = nn.fit_predict(X2.copy(), Xe2.copy(), Xm2.copy(), z, ze, rstate=np.random.RandomState(2), k=6, label_dict=pd,
+                                    return_gof=True, save_fits=False, verbose=False)
+    q2, (qm2, qe2) = sharded.sharded_fit_predict(nn, X2.copy(), Xe2.copy(), Xm2.copy(), z, ze, gather='pdfs', chunks=4, label_dict=pd,
+                                                 save_fits=False, rstate=np.random.RandomState(2), k=6, rounds_on_one_rank=True)
+    np.testing.assert_allclose(q2, p2, rtol=1e-12, atol=1e-16)
+    np.testing.assert_array_equal(qm2, lm2)
+    dist.destroy_process_group()
+    print("OVERLAPPED_RCCL_ONE_RANK_OK ms_compute=%.2f ms_fence=%.3f" % (sharded.last_stats['ms_compute'], sharded.last_stats['ms_fence']))
+
+
 if __name__ == '__main__':
     check_stream_contract()
     check_knn_device_resident()
     check_prepared_handle_survives_other_fitters()
+    check_overlapped_rounds_through_rccl_on_one_rank()

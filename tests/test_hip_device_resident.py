@@ -25,10 +25,11 @@ def problem(N, M, seed):
 
 def test_torch_side_checks_in_a_fresh_process():
     """stream contract (a call under fz_set_producer_stream returns while another stream still spins; the default drains the
-    device), NearestNeighbors with device tensors / out= / query_features, prepared handles on the shared engine"""
+    device), NearestNeighbors with device tensors / out= / query_features, prepared handles on the shared engine, and the whole
+    overlapped sharded call (BruteForce and NearestNeighbors) through RCCL in a one-rank group"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, os.path.join(HERE, '_gpu_torch_checks.py')], capture_output=True, text=True, timeout=900, env=env)
-    for marker in ('STREAM_CONTRACT_OK', 'KNN_DEVICE_RESIDENT_OK', 'PREPARED_HANDLE_OK'):
+    for marker in ('STREAM_CONTRACT_OK', 'KNN_DEVICE_RESIDENT_OK', 'PREPARED_HANDLE_OK', 'OVERLAPPED_RCCL_ONE_RANK_OK'):
         assert marker in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
