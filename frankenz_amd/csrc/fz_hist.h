@@ -148,6 +148,20 @@ __device__ __forceinline__ float wave_maxf_dpp(float v) {
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
+// wave-wide maximum of a POSITIVE double to 20 mantissa bits: positive doubles order like their high words, so an integer maximum
+// of the high words (DPP within rows, the four row results through scalar registers: ~12 instructions, no LDS crossbar) gives
+// the maximum rounded DOWN to a multiple of 2^-20 of itself -- a lower bound, which is what its use wants
+__device__ __forceinline__ double wave_max_pos_hi(double v) {
+    int x = __double2hiint(v);
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return __hiloint2double(mx(mx(a, b), mx(c, d)), 0);
+}
+
 template <int TW>
 struct HistState {
     double S[TW];            // per lane, EXACT: sum of the weights
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                     hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
                                     // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
                                     // what still waits in the buffer only raises it)
-                                    hs.wamb[o] = uniform_d(wave_max(hs.wmx[o]) * (wt_thresh * 0.999));
+                                    hs.wamb[o] = wave_max_pos_hi(hs.wmx[o]) * (wt_thresh * 0.999);
                                 }
                             }
 #pragma unroll
