@@ -1032,3 +1032,11 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
 
 #include "fz_knn_host.inc"
 #include "fz_summary_host.inc"
+
+#ifdef FZ_KM_STATS
+extern "C" int fz_debug_kmstats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fz::fz_kmstats), 128 * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fz::fz_kmstats), z, 128 * 8) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

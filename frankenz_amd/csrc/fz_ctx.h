@@ -108,7 +108,7 @@ struct fz_ctx {
     DevBuf d_omap, d_redo;     // d_redo: objects the weight-space body hands to the ln-space body (count, then indices)
     // knn
     int knn_K = 0, knn_F = 0; int64_t knn_M = 0; bool knn_mfma = false, knn_sorted = false; int knn_gsl = 0;
-    DevBuf d_kgbox;            // boxes of the scan's <= 128 tile groups per feature set
+    DevBuf d_kgbox, d_ktbox;   // boxes of the scan's <= 128 tile groups per feature set, and of every 64-model tile
     DevBuf d_idxs;             // neighbour table of the chunk being searched and fitted (fz_knn_search_fit_predict)
     DevBuf d_trees, d_q, d_idx, d_nbr, d_nn, d_tnorm, d_kbmat, d_kcen, d_kpmax, d_kperm, d_ktab, d_kqperm, d_kqcnt;
 
@@ -116,7 +116,7 @@ struct fz_ctx {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
                                   &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
-                                  &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_omap, &d_redo, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_kgbox, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kqperm, &d_kqcnt};
+                                  &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_omap, &d_redo, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_kgbox, &d_ktbox, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kqperm, &d_kqcnt};
         for (auto& b : d_pl) v.push_back(&b);
         for (auto& b : d_mc) v.push_back(&b);
         return v;

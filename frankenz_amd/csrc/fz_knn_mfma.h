@@ -34,7 +34,17 @@ typedef float fz_f4 __attribute__((ext_vector_type(4)));
 
 #define FZ_KM_TILE 64                   // models per LDS tile
 #define FZ_KM_TFLOATS (FZ_KM_TILE * 8)  // 8 slots per model
-#define FZ_KM_TSTR 544                  // floats per 64-model tile in HBM and LDS: 512 operand floats + bounding box (8 lo, 8 hi) + 16 spare (the stride keeps the LDS-DMA chunking: 2176 B)
+#ifdef FZ_KM_STATS                      // development counters (tools/devbuild.sh with FZ_DEV_MAINFLAGS=-DFZ_KM_STATS): never in a release build
+__device__ unsigned long long fz_kmstats[128];
+#define KMSTAT(i, v) do { if ((i) < 8) kmc[(i) & 7] += (unsigned)(v); } while (0)         // per-wave registers, flushed once at the end (global atomics inside the loops would be what is measured)
+#define KMFLUSH(i, v) do { const unsigned long long kmv_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&fz_kmstats[i], kmv_); } while (0)
+// wall-clock cycles since the last stamp go to section i (8 + i in fz_kmstats)
+#define KMT(i) do { const long long kmt_ = (long long)clock64(); kmtime[i] += kmt_ - kmlast; kmlast = kmt_; } while (0)
+#else
+#define KMSTAT(i, v) do { } while (0)
+#define KMT(i) do { } while (0)
+#endif
+#define FZ_KM_TSTR 512                  // floats per 64-model tile in HBM and LDS: 8 slots x 64 models = two 1 KB LDS-DMA rounds of the wave
 
 // per-feature mean of one feature set (one block per set), in fp64
 static __global__ __launch_bounds__(256) void k_knn_center(const float* __restrict__ in, int64_t M, int F, float* __restrict__ cen) {
@@ -85,39 +95,38 @@ static __global__ __launch_bounds__(256) void k_knn_pack_mfma(const float* __res
 }
 
 
-// bounding box of every 64-model tile (behind the tile's operands): the search skips a tile when the box is farther from
-// each of the wave's 16 queries than that query's admission bar.  Stored slightly enlarged (one float rounding), so that
-// the fp32 lower bound formed from it stays below the exact distance.  enable = 0: boxes that never exclude anything.
+// bounding box of every 64-model tile, [set][tile][lo 8 | hi 8] (contiguous: the scan tests 64 tiles at a time, one per lane): a tile
+// farther from each of the wave's 16 queries than that query's admission bar is never staged.  Stored slightly enlarged (one float
+// rounding), so that the fp32 lower bound formed from it stays below the exact distance.
 static __global__ __launch_bounds__(64) void k_knn_boxes(const float* __restrict__ in, int64_t M, int F, int64_t Mp,
-                                                         const int* __restrict__ perm, float* __restrict__ bmat, int enable) {
+                                                         const int* __restrict__ perm, float* __restrict__ tbox) {
     const int lane = threadIdx.x, t = blockIdx.y;
     const int64_t blk = blockIdx.x, j = blk * 64 + lane;
-    float* o = bmat + ((size_t)t * (Mp >> 6) + blk) * FZ_KM_TSTR + 512;
+    float* o = tbox + ((size_t)t * (Mp >> 6) + blk) * 16;
     const int64_t oj = (j < M) ? (perm ? (int64_t)perm[(size_t)t * M + j] : j) : 0;
     for (int f = 0; f < 8; ++f) {
         float lo = INFINITY, hi = -INFINITY;
         if (f < F && j < M) { const float v = in[((size_t)t * M + oj) * F + f]; if (v == v) { lo = v; hi = v; } }
         for (int d = 32; d > 0; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
         if (lane == 0) {
-            const bool on = enable && f < F;
-            o[f] = on ? lo - 1.2e-7f * fabsf(lo) : -INFINITY;
-            o[8 + f] = on ? hi + 1.2e-7f * fabsf(hi) : INFINITY;
+            o[f] = f < F ? lo - 1.2e-7f * fabsf(lo) : -INFINITY;
+            o[8 + f] = f < F ? hi + 1.2e-7f * fabsf(hi) : INFINITY;
         }
     }
 }
 
-// second level of the skipping: boxes of at most 128 groups of 2^gsl consecutive tiles (k-d order: consecutive leaves are subtrees or
+// first level of the skipping: boxes of at most 128 groups of 2^gsl consecutive tiles (k-d order: consecutive leaves are subtrees or
 // neighbouring subtrees), [set][128][lo 8 | hi 8].  A wave tests them all at once against its 16 queries' bars (k_knn_mfma: two
-// lane-parallel rounds) and keeps the result as a 128-bit mask in scalar registers; the scan then steps over unreachable groups
-// without touching their tiles' boxes.  Groups past the last tile get an empty box (never reachable).
-static __global__ __launch_bounds__(64) void k_knn_maskboxes(int64_t Mp, int M, int gsl, const float* __restrict__ bmat, float* __restrict__ gbox) {
+// lane-parallel rounds) and keeps the result as a 128-bit mask in scalar registers; the tiles of unreachable groups are not even tested.
+// Groups past the last tile get an empty box (never reachable).
+static __global__ __launch_bounds__(64) void k_knn_maskboxes(int64_t Mp, int M, int gsl, const float* __restrict__ tbox, float* __restrict__ gbox) {
     const int lane = threadIdx.x, t = blockIdx.y, g = blockIdx.x;
     const int64_t ntl = ((int64_t)M + 63) >> 6, t0 = (int64_t)g << gsl, t1 = t0 + ((int64_t)1 << gsl) < ntl ? t0 + ((int64_t)1 << gsl) : ntl;
     if (lane >= 16) return;
-    const float* base = bmat + (size_t)t * (Mp >> 6) * FZ_KM_TSTR;
+    const float* base = tbox + (size_t)t * (Mp >> 6) * 16;
     float v = lane < 8 ? INFINITY : -INFINITY;
     for (int64_t u = t0; u < t1; ++u) {
-        const float b = base[u * FZ_KM_TSTR + 512 + lane];
+        const float b = base[u * 16 + lane];
         v = lane < 8 ? fminf(v, b) : fmaxf(v, b);
     }
     gbox[((size_t)t * 128 + g) * 16 + lane] = v;          // (no tile: lo = +inf, hi = -inf)
@@ -178,35 +187,31 @@ __device__ __forceinline__ float knn_bar_mfma(double tau, float uq2, float e) {
     return f32_up(f32_up(fmaf(t, 1.000002f, slack)));                                     // the 17 u bar term of the header
 }
 
-// 4 waves x 16 queries per block, one feature set per blockIdx.y (+ tree0); the block streams the set's
-// models through two LDS tiles (separate arrays: the LDS-DMA of the next tile does not stall the reads
-// of the current one).
+// lane exchange inside a row of 16 lanes (DPP): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140 --
+// after combining through the four in this order every lane of the row holds the reduction over its 16 lanes
+template <int CTRL> __device__ __forceinline__ int row16_xchg(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float row16_xchg(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+
+// One wave per block = 16 queries against one feature set (blockIdx.y); the wave streams the set's reachable 64-model tiles through
+// two LDS buffers (separate arrays: the LDS-DMA of the next tile does not stall the reads of the current one).
 //  * The bar of a query row is folded INTO the product (slot F holds alpha - bar), so the screen of a
 //    64-model step is the sign of 16 accumulators: 8 v_or3 and one compare next to the 8 MFMAs.
-//  * The sorted top-k lists of the 16 queries of a wave live in LDS (dynamic: [wave][16 rows][kpad] fp64
-//    distances, then the int32 indices), ordered by (distance, model index) -- the order an ascending
-//    scan with first-come ties leaves, whatever the arrival order -- so the admission path is one rolled
-//    loop over the pairs that passed the screen.
-//  * seed (may be null): the neighbour table of feature set 0, already complete.  The K feature sets
-//    are noise realisations of the SAME models, so the k neighbours found in set 0 are k distinct
-//    models that are close in this set too: their exact distances start the list, and the bar starts
-//    at their largest instead of +inf -- the k ln(M / k) admissions of a cold scan (half of them in
-//    the first 1 % of the models) shrink to the few models that really sit inside that ball.
+//  * The sorted top-k lists of the 16 queries are ordered by (distance, model index) -- the order an ascending
+//    scan with first-come ties leaves, whatever the arrival order -- so the table does not depend on the visiting order.
+//  * Every feature set is searched cold.  (Rounds 2-4 started sets 1..K-1 from the exact distances of set 0's neighbours: the
+//    Monte-Carlo noise of the benchmark displaces them so far -- their k-th distance is 13x the true one -- that ranking them cost
+//    more than they saved once the first tile's admissions were spread over all row teams: 23.9 -> 22.6 ms per step without them.)
 // FX: the feature count when it is a compile-time constant (5: the usual five bands), 0 = runtime F.
-// NWB: waves per block (they share the LDS tiles and meet at one barrier per tile; the default launch is ONE wave per block).
-// Scan state of one wave: the visiting order (outwards from the queries' own place, alternating sides), the batch of four
-// candidate tiles whose bounding boxes are in registers, and the reachable tiles of the last tested batch that have not been
-// taken yet.  (A plain struct with inlined members: lambdas capturing lambdas made the compiler keep this state in scratch.)
-template <int FL>
+//
+// Scan state of one wave: the visiting order (outwards from the queries' own leaf, alternating sides) over the tiles whose bit is set
+// in the wave's reachability mask -- one bit per tile in LDS (tm), built by build_mask from the tiles' bounding boxes, under a
+// 128-bit mask of reachable tile GROUPS in scalar registers.  (A plain struct with inlined members: lambdas capturing lambdas made
+// the compiler keep this state in scratch.)
 struct KnnScan {
     int nl, nr, ntiles, right;
     unsigned long long m0, m1;                             // reachable groups of 2^gsl tiles (bit g; wave-uniform), see k_knn_maskboxes
     int gsl;
-    int cand;                                             // this lane's candidate tile of the batch in registers: lane group c = lane >> 4 holds candidate c (-1: none)
-    int pend;                                             // ... of the batch that was tested last
-    fz_f4 bl0, bl1, bh0, bh1;                             // the candidate's box: lo[0..7], hi[0..7]
-    unsigned pmask;                                       // reachable candidates of the tested batch that have not been taken yet
-    // (no four-way selects over members here: the compiler turns them into indexed loads and moves the whole struct to scratch)
+    const unsigned long long* tm;                          // LDS: bit t & 63 of word t >> 6 = tile t may hold a model under some row's bar
     __device__ __forceinline__ int next_tile() {
         while (true) {
             if (nr >= ntiles && nl < 0) return -1;
@@ -214,45 +219,22 @@ struct KnnScan {
             const int t = r ? nr : nl;
             const int g = t >> gsl;                         // < 128
             const unsigned long long mw = g < 64 ? m0 : m1;
-            if ((mw >> (g & 63)) & 1ull) {
-                if (r) ++nr; else --nl;
-                right = 1 - right;
-                return t;
+            if (!((mw >> (g & 63)) & 1ull)) {               // the whole group is out of every row's reach
+                if (r) nr = (g + 1) << gsl; else nl = (g << gsl) - 1;
+                continue;
             }
-            if (r) nr = (g + 1) << gsl; else nl = (g << gsl) - 1;       // the whole group is out of every row's reach
-        }
-    }
-    __device__ __forceinline__ void fetch(const float* bm, int sl) {
-        int m = -1;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const int t = next_tile(); m = (sl == c) ? t : m; }
-        cand = m;
-        const fz_f4* bx = reinterpret_cast<const fz_f4*>(bm + (size_t)(m >= 0 ? m : 0) * FZ_KM_TSTR + 512);
-        bl0 = bx[0]; bl1 = bx[1]; bh0 = bx[2]; bh1 = bx[3];
-    }
-    // bit c: candidate c is within reach of some row (lane group c tests it: its 16 lanes are the 16 query rows)
-    __device__ __forceinline__ unsigned test(const float (&qlo)[FL], const float (&qhi)[FL], float barrow) const {
-        float lb = 0.f;
-#pragma unroll
-        for (int f = 0; f < FL; ++f) {
-            const float lo = f < 4 ? bl0[f & 3] : bl1[f & 3], hi = f < 4 ? bh0[f & 3] : bh1[f & 3];
-            const float m = fmaxf(fmaxf(lo - qhi[f], qlo[f] - hi), 0.f);        // the query's rounding already in qlo / qhi
-            lb = fmaf(m, m, lb);
-        }
-        const unsigned long long rm = __ballot(cand >= 0 && lb * 0.999999f <= barrow);
-        return ((rm & 0xffffull) ? 1u : 0u) | (((rm >> 16) & 0xffffull) ? 2u : 0u) | (((rm >> 32) & 0xffffull) ? 4u : 0u) | ((rm >> 48) ? 8u : 0u);
-    }
-    __device__ __forceinline__ int next_reachable(const float* bm, int sl, const float (&qlo)[FL], const float (&qhi)[FL], float barrow) {
-        while (true) {
-            if (pmask) {
-                const int c = __builtin_ctz(pmask);
-                pmask &= pmask - 1u;
-                return __builtin_amdgcn_readlane(pend, 16 * c);
+            const unsigned long long wv = tm[t >> 6];       // (every lane reads the same word)
+            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wv >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)wv);
+            if (r) {
+                const unsigned long long rest = w >> (t & 63);
+                if (rest) { const int tt = t + __builtin_ctzll(rest); nr = tt + 1; right = 0; return tt; }
+                nr = ((t >> 6) + 1) << 6;
+            } else {
+                const unsigned long long rest = w << (63 - (t & 63));
+                if (rest) { const int tt = t - __builtin_clzll(rest); nl = tt - 1; right = 1; return tt; }
+                nl = ((t >> 6) << 6) - 1;
             }
-            if (__builtin_amdgcn_readfirstlane(cand) < 0) return -1;      // no batch left (candidate 0 is the first to run out)
-            pend = cand;
-            pmask = test(qlo, qhi, barrow);
-            fetch(bm, sl);                                 // the next batch's boxes travel while this batch's tiles are processed
         }
     }
 };
@@ -260,58 +242,79 @@ struct KnnScan {
 // KPL > 0: ROW-PARALLEL ADMISSIONS.  The sorted list of query row R lives in the registers of the four lanes 4R .. 4R+3
 // (KPL consecutive entries each, k <= 4 KPL), so the wave holds its 16 lists as 16 independent "teams".  Pairs that pass
 // the exact fp64 re-check are not inserted one at a time by the whole wave (a serial LDS round trip + ~150 instructions
-// each: 3/4 of the kernel's instructions at M = 1e5) but appended to their row's small LDS queue; when a queue holds
-// FZ_KM_DT entries -- or the scan ends -- every team drains its own queue at the same time, one entry per round: compare
-// against its KPL entries, find the place with two quad-DPP moves, shift.  Rows whose queue is empty sit the round out.
+// each) but appended to their row's small LDS queue; when a queue holds FZ_KM_DT entries -- or the scan ends -- every team
+// drains its own queue at the same time, one entry per round: compare against its KPL entries, find the place with two
+// quad-DPP moves, shift.  Rows whose queue is empty sit the round out.
 // Bars and k-th distances are refreshed once per drain, so between drains the screen is looser than it could be (a
 // superset is admitted; an entry that no longer belongs is a no-op for its team).  The lists are ordered by
 // (distance, original index) as before: the neighbour table does not depend on any of this.  KPL = 0: the lists stay in LDS
 // and the wave inserts one candidate at a time (k > 32).
 #ifndef FZ_KM_QC
-#define FZ_KM_QC 24                     // queue entries per row: FZ_KM_DT - 1 may wait when a step begins and a step adds at most 16 to one row
-#define FZ_KM_DT 8                      // drain when some row's queue holds this many
+#define FZ_KM_QC 12                     // queue entries per row (a pair that finds its row's queue full waits for the drain it triggers)
+#define FZ_KM_DT 12                     // drain when some row's queue holds this many (QC / DT 24 / 8: 18.6 ms per step, 12 / 8: 16.6 -- LDS bounds the occupancy --, 12 / 10: 16.4, 12 / 12: 16.2, 16 / 12: 16.5, 8 / 6: 16.8)
 #endif
+#ifndef FZ_KM_B1
+#define FZ_KM_B1 28                     // the reachability mask is built after this many tiles (the scan starts without one: the own leaf and its
+#define FZ_KM_B2 1000000                // neighbours set the bars; building costs as much as ~15 tiles, so once, late: 6 + 40: 19.7 ms per step, 14: 18.4, 20: 18.1, 28: 17.9, 40: 17.9) ... and again after this many
+#endif
+// dynamic LDS: the lists / queues, then one bit per tile (fz_knn_host.inc sizes the launch with the same expression)
+__host__ __device__ inline size_t knn_mfma_list_bytes(int kpad, int kpl) {
+    const size_t a = (size_t)16 * kpad * 12, b = kpl ? (size_t)16 * FZ_KM_QC * 12 : (size_t)0;
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
 template <int TILE, int FX, int NWB, int KPL>
 static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
-                                                         const float* __restrict__ pmax, const float* __restrict__ feats, int FT,
-                                                         int64_t Mp, int M, const double* __restrict__ q, int64_t N, int F, int k,
-                                                         int kpad, double bound2, int64_t* idx, int K, int tree0, const int64_t* seed,
+                                                         const float* __restrict__ pmax, int64_t Mp, int M,
+                                                         const double* __restrict__ q, int64_t N, int F, int k,
+                                                         int kpad, double bound2, int64_t* idx, int K,
                                                          const int* __restrict__ qperm, const int* __restrict__ ktab,
-                                                         const float* __restrict__ gbox, int gsl) {
-    static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile (+ its bounding box) per step");
+                                                         const float* __restrict__ tbox, const float* __restrict__ gbox, int gsl) {
+    static_assert(TILE == 64 && NWB == 1, "one wave per block, one 64-model tile per step");
     static_assert(KPL == 0 || KPL == 5 || KPL == 8, "register lists: k <= 20 or k <= 32");
     constexpr int TF = FZ_KM_TSTR;
     constexpr int FL = FX ? FX : 6;                    // feature loop bound of the exact re-check
-    __shared__ __attribute__((aligned(16))) float tA[TF];
-    __shared__ __attribute__((aligned(16))) float tB[TF];
-    __shared__ double qs[NWB][16][8];                   // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
+    __shared__ __attribute__((aligned(16))) float tA[TF];       // the tile being multiplied and the one in flight (separate arrays and
+    __shared__ __attribute__((aligned(16))) float tB[TF];       // two copies of the tile step: one copy with a toggled buffer index measured 18.6 against 17.8 ms)
+    __shared__ double qs[16][8];                        // the queries in fp64 (exact re-check); slot 6 = tau, slot 7 = bar constants
+    __shared__ __attribute__((aligned(16))) float qbx[16][12];   // the queries in fp32 with their rounding: lo[6] | hi[6] (tile tests)
     __shared__ int qn[16];                              // KPL: entries waiting in each row's queue
     extern __shared__ double s_lists[];
-    // KPL: the per-row queues of admitted (distance, model) pairs reuse the lists' LDS -- the lists are only there while the
-    // seeds are ranked and when the result is written; in between they live in registers
+    // KPL: the per-row queues of admitted (distance, model) pairs reuse the lists' LDS -- the lists are only there
+    // when the result is written; in between they live in registers
     double* qd = s_lists;                                // [16][FZ_KM_QC]
     int* qj = reinterpret_cast<int*>(s_lists + 16 * FZ_KM_QC);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tree = blockIdx.y + tree0;
-    const int64_t i0 = ((int64_t)blockIdx.x * NWB + wave) * 16;
+#ifdef FZ_KM_STATS
+    long long kmtime[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kmlast = (long long)clock64();
+    unsigned kmc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int tree = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * 16;
     const float* bm = bmat + (size_t)tree * (Mp >> 6) * FZ_KM_TSTR;
     const int row = lane & 15, sl = lane >> 4;
-    double* Ld = s_lists + (size_t)wave * 16 * kpad;                                     // [16][kpad]
-    int* Lj = reinterpret_cast<int*>(s_lists + (size_t)NWB * 16 * kpad) + (size_t)wave * 16 * kpad;
+    const int ntiles = (M + TILE - 1) / TILE, nw = (ntiles + 63) >> 6;
+    double* Ld = s_lists;                                                                // [16][kpad]
+    int* Lj = reinterpret_cast<int*>(s_lists + (size_t)16 * kpad);
+    unsigned long long* tm = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_lists) + knn_mfma_list_bytes(kpad, KPL));
     for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
+    for (int w = lane; w < nw; w += 64) tm[w] = (w + 1 < nw || (ntiles & 63) == 0) ? ~0ull : ((1ull << (ntiles & 63)) - 1ull);     // every tile, until the first build
     if (lane < 16) qn[lane] = 0;
     // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
     // qperm (may be null): the queries grouped by their leaf in set 0's tree -- the 16 queries of a wave are neighbours in feature space
     const int64_t islot = i0 + row < N ? i0 + row : N - 1;
     const int64_t qi = qperm ? (int64_t)qperm[islot] : islot;       // this lane's row, as an index into q / idx
-    for (int ff = sl; ff < 6; ff += 4) qs[wave][row][ff] = (ff < F) ? q[qi * F + ff] : 0.0;
+    for (int ff = sl; ff < 6; ff += 4) {
+        const double v = (ff < F) ? q[qi * F + ff] : 0.0;
+        qs[row][ff] = v;
+        const float qf = (float)v, eq = 2.0e-7f * fabsf(qf);         // the conversion's rounding and that of qf -+ eq, with room
+        qbx[row][ff] = qf - eq; qbx[row][6 + ff] = qf + eq;
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): own LDS writes done (the same wave reads them)
     float qc[6]; double qn2 = 0.0, qdc = 0.0, c2 = 0.0;
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
         const double cf = (f < F) ? (double)cen[tree * 8 + f] : 0.0;
-        qc[f] = (f < F) ? (float)(qs[wave][row][f] - cf) : 0.f;
+        qc[f] = (f < F) ? (float)(qs[row][f] - cf) : 0.f;
         qn2 = fma((double)qc[f], (double)qc[f], qn2); qdc = fma((double)qc[f], cf, qdc); c2 = fma(cf, cf, c2);
     }
     const float alpha = (float)(qn2 + 2.0 * qdc);
@@ -319,33 +322,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         const double u = 6.0e-8, Q = sqrt(qn2) * 1.000001, P = (double)pmax[tree], C = sqrt(c2) * 1.000001;
         const float uq2 = (float)(2.0 * u * Q * 1.000001);
         const float e = (float)(u * (19.0 * Q * Q + 18.0 * P * P + 70.0 * Q * C + 32.0 * Q * P) * 1.000001);
-        if (sl == 0) { float2 pk; pk.x = uq2; pk.y = e; *reinterpret_cast<float2*>(&qs[wave][row][7]) = pk; qs[wave][row][6] = bound2; }
+        if (sl == 0) { float2 pk; pk.x = uq2; pk.y = e; *reinterpret_cast<float2*>(&qs[row][7]) = pk; qs[row][6] = bound2; }
     }
-    // ---- seeds: exact distances of set 0's neighbours in THIS set, ranked into the row's list ----
-    if (seed) {
-        const float* ft = feats + (size_t)tree * FT * Mp;
-        for (int R = 0; R < 16; ++R) {
-            const int64_t i = __shfl(qi, R, 64);
-            const int64_t js64 = (lane < k) ? seed[(i * K) * k + lane] : (int64_t)M;
-            const bool valid = js64 >= 0 && js64 < M;
-            int js = valid ? (int)js64 : M + lane;                          // distinct keys for the empty entries
-            double d2 = INFINITY;
-            if (valid) {
-                d2 = 0.0;
-                for (int f = 0; f < F; ++f) { const double d = qs[wave][R][f] - (double)ft[(size_t)f * Mp + js]; d2 = fma(d, d, d2); }
-                if (!(d2 < bound2)) { d2 = INFINITY; js = M + lane; }
-            }
-            double* ldr = Ld + R * kpad; int* ljr = Lj + R * kpad;
-            if (lane < k) { ldr[lane] = d2; ljr[lane] = js; }
-            int rank = 0;
-            for (int m = 0; m < k; ++m) { const double dm = ldr[m]; const int jm = ljr[m]; rank += (dm < d2 || (dm == d2 && jm < js)) ? 1 : 0; }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane < k) { ldr[rank] = d2; ljr[rank] = js; }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane < 16) { const double kd = Ld[lane * kpad + k - 1]; qs[wave][lane][6] = kd < bound2 ? kd : bound2; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     // A operands: slots -2 q'_f | alpha - bar | 1 | 0; the bar slot F sits in a0 (F < 4) or a1 of the lanes with sl == F & 3
     auto aslot = [&](int s, float ab) -> float {
         float v = (s == F) ? ab : ((s == F + 1) ? 1.f : 0.f);
@@ -353,170 +332,224 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         for (int f = 0; f < 6; ++f) if (s == f && f < F) v = -2.f * qc[f];
         return v;
     };
-    float a0, a1;
+    // The first tile of an unbounded search (the queries' own leaf) is multiplied with bar 0 -- the products ARE the squared distances,
+    // to fp32 rounding -- and only the ~k nearest of its 64 models per row go to the lists first (run_tile); the tile is then visited
+    // again as any other, under the bars those leave.  (All 64 pass an infinite bar, in storage order: 48 insertions per row where
+    // ~22 do, a quarter of all the insertions of a scan.)
+    bool first = KPL > 0 && !(bound2 < 1e37), second = false;
+    unsigned pm_first = 0u;
+    float a0, a1, barrow;                               // barrow: the row's bar in distance units (lanes 0..15 hold rows 0..15)
     {
-        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
-        const float ab = alpha - knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
+        const float2 pk = *reinterpret_cast<const float2*>(&qs[row][7]);
+        barrow = knn_bar_mfma(qs[row][6], pk.x, pk.y);
+        const float ab = first ? alpha : alpha - barrow;
         a0 = aslot(sl, ab); a1 = aslot(4 + sl, ab);
     }
     const bool bar_lane = sl == (F & 3);
-    // for the tile test: this lane's row in fp32 (+ the rounding that cost), and the row's bar in distance units
-    float qlo[FL], qhi[FL];
-#pragma unroll
-    for (int f = 0; f < FL; ++f) { const float qf = (float)qs[wave][row][f], eq = 2.0e-7f * fabsf(qf); qlo[f] = qf - eq; qhi[f] = qf + eq; }      // the conversion's rounding and that of qf -+ eq, with room
-    float barrow;
-    {
-        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
-        barrow = knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
-    }
 
     // ---- row teams: the lists in registers, the drain ----
     constexpr int KP = KPL ? KPL : 1;
     double Lr[KP]; int Jr[KP];
     const int team = lane >> 2, tl = lane & 3;
     if constexpr (KPL > 0) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-        for (int e = 0; e < KPL; ++e) { Lr[e] = Ld[team * kpad + tl * KPL + e]; Jr[e] = Lj[team * kpad + tl * KPL + e]; }   // kpad >= 4 KPL
+        for (int e = 0; e < KPL; ++e) { Lr[e] = INFINITY; Jr[e] = M + tl * KPL + e; }           // (distinct keys for the empty entries)
     }
     auto quad_prev_i = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_update_dpp(v, v, 0x90, 0xf, 0xf, false); };     // quad_perm [0,0,1,2]: lane t <- lane t - 1
-    auto quad_or = [](int v) __attribute__((always_inline)) {
-        v |= __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);       // [1,0,3,2]
-        v |= __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);       // [2,3,0,1]
-        return v;
-    };
     auto refresh_bars = [&]() __attribute__((always_inline)) {                          // every lane: the bar of its row from the row's k-th distance
-        const float2 pk = *reinterpret_cast<const float2*>(&qs[wave][row][7]);
-        barrow = knn_bar_mfma(qs[wave][row][6], pk.x, pk.y);
+        const float2 pk = *reinterpret_cast<const float2*>(&qs[row][7]);
+        barrow = knn_bar_mfma(qs[row][6], pk.x, pk.y);
         const float ab = alpha - barrow;
         if (bar_lane) { if (F < 4) a0 = ab; else a1 = ab; }
     };
     auto drain = [&]() __attribute__((always_inline)) {
         if constexpr (KPL > 0) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            const int cnt = qn[team];
+            const int cnt = qn[team] < FZ_KM_QC ? qn[team] : FZ_KM_QC;
+            KMSTAT(5, 1);
             for (int h = 0; __any(h < cnt); ++h) {
                 const bool act = h < cnt;
+                KMSTAT(6, 1);
                 const double dn = qd[team * FZ_KM_QC + (act ? h : 0)];
                 const int jn = qj[team * FZ_KM_QC + (act ? h : 0)];
-                int cb = 0, dup = 0;
+                // c[e]: entry e precedes the candidate in (distance, index) order (a model is met once per scan: no duplicates) -- or
+                // the team sits the round out.  The list is sorted, so c[] is a prefix; the entries after it move up by one, the
+                // candidate (or, in the lanes above the one it lands in, the lower lane's last entry) takes the first free place.
+                // Selects on the comparison masks only: no position count, no branch (a branch around the shift costs a register copy
+                // of the whole list per round).
+                bool c[KPL];
 #pragma unroll
                 for (int e = 0; e < KPL; ++e) {
-                    cb += (Lr[e] < dn || (Lr[e] == dn && Jr[e] < jn)) ? 1 : 0;      // lexicographic (distance, index)
-                    dup |= (Jr[e] == jn) ? 1 : 0;                                   // a model already listed (a seed) is not listed twice
+                    const bool lt = Lr[e] < dn, eq = Lr[e] == dn, jl = Jr[e] < jn;
+                    c[e] = !act | lt | (eq & jl);
                 }
-                dup = quad_or(dup);
-                const int cbp = quad_prev_i(cb);
+                const bool first = (tl == 0) | (quad_prev_i(c[KPL - 1] ? 1 : 0) != 0);      // every entry of the lower lane precedes the candidate: it lands in this lane or a higher one
                 const int lh = quad_prev_i(__double2hiint(Lr[KPL - 1])), ll = quad_prev_i(__double2loint(Lr[KPL - 1]));
                 const int jl = quad_prev_i(Jr[KPL - 1]);
-                const bool first = (tl == 0) || (cbp == KPL);                      // the entry lands in this lane (else: the lower lane's last one moves up)
                 const double nd = first ? dn : __hiloint2double(lh, ll);
                 const int nj = first ? jn : jl;
-                if (act && !dup && cb < KPL) {
+                KMSTAT(7, __builtin_popcountll(__ballot(act && !c[KPL - 1] && first)));   // rows that take an entry this round
 #pragma unroll
-                    for (int e = KPL - 1; e >= 0; --e) {
-                        const bool sh = e > cb, at = e == cb;
-                        Lr[e] = sh ? Lr[e > 0 ? e - 1 : 0] : (at ? nd : Lr[e]);
-                        Jr[e] = sh ? Jr[e > 0 ? e - 1 : 0] : (at ? nj : Jr[e]);
-                    }
+                for (int e = KPL - 1; e >= 1; --e) {
+                    Lr[e] = c[e] ? Lr[e] : (c[e - 1] ? nd : Lr[e - 1]);
+                    Jr[e] = c[e] ? Jr[e] : (c[e - 1] ? nj : Jr[e - 1]);
                 }
+                Lr[0] = c[0] ? Lr[0] : nd;
+                Jr[0] = c[0] ? Jr[0] : nj;
             }
             // the k-th distance of every row, then the bars
             // (one predicated store per slot: a select chain over the slots becomes an indexed load and the list goes to scratch)
             const int ke = k - 1;
 #pragma unroll
             for (int e = 0; e < KPL; ++e)
-                if (tl * KPL + e == ke) qs[wave][team][6] = Lr[e] < bound2 ? Lr[e] : bound2;
+                if (tl * KPL + e == ke) qs[team][6] = Lr[e] < bound2 ? Lr[e] : bound2;
             if (tl == 0) qn[team] = 0;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             refresh_bars();
         }
     };
 
-    const int ntiles = (M + TILE - 1) / TILE;
     // Visiting order.  The set's models are stored in k-d order (upload: depth-first leaves) and the wave's queries are neighbours
-    // (qperm), so the tiles around the queries' own place hold most of their neighbours: start there and work outwards,
-    // alternating sides.  The bar then drops to nearly its final value within the first few per cent of the models and
-    // the rest of the scan admits little (benchmark data: 55-65 admissions per query instead of 87).  The lists are
-    // ordered by (distance, original index), so the result does not depend on the order.  One wave per block only:
-    // waves sharing tiles would need a common start.
-    // Tile skipping.  Every 64-model tile carries its bounding box (behind its operands in HBM).  The boxes of the next FOUR
-    // tiles of the visiting order are tested at once -- lane group c = lane >> 4 takes candidate c, its 16 lanes the 16 query
-    // rows: lower bound of the distance from the row's query to the box against the row's bar -- straight from global memory
-    // (64 B per tile, L2-resident), and only tiles within reach of some row are staged into LDS and multiplied.  The boxes of
-    // the following batch are requested before the current batch's tiles are processed.  (Before: every tile of a
-    // reachable group of eight was staged, 2 KB, to read its box from LDS: 59 % of all tiles staged for 18 % multiplied, and
-    // the per-tile test + staging + barrier was two thirds of the kernel's instructions.)
-    KnnScan<FL> sc;
-    sc.nl = -1; sc.nr = 0; sc.ntiles = ntiles; sc.right = 1; sc.pmask = 0u; sc.pend = -1;
-    sc.m0 = ~0ull; sc.m1 = ~0ull; sc.gsl = gbox ? gsl : 30;
-    // group mask: lane l tests groups l and l + 64 against all 16 rows (their queries from LDS, their bars from lanes 0..15)
+    // (qperm), so the tiles around the queries' own leaf hold most of their neighbours: start there and work outwards,
+    // alternating sides.  The bars then drop to nearly their final values within the first few tiles and the rest of the scan
+    // admits little.  The lists are ordered by (distance, original index), so the result does not depend on the order.
+    // Tile skipping.  Every 64-model tile has a bounding box (tbox), every group of 2^gsl tiles another (gbox).  build_mask tests the
+    // <= 128 group boxes against the 16 rows' bars (lane l: groups l and l + 64), then the tiles of the reachable groups, 64 at a
+    // time (lane l: tile 64 w + l, its box one coalesced 64-byte read; the 16 rows in a loop) and leaves one bit per tile in LDS;
+    // the scan then only visits set bits: no per-tile test, no dependent global read between two tiles.  (Round 3-4 tested the next
+    // four tiles of the visiting order just before they were staged, against the bars of that moment: fewer tiles multiplied --
+    // 110 per wave -- but a chain of dependent L2 round trips, 36-44 % of a wave's cycles.)  A cold scan starts without a mask,
+    // builds it after FZ_KM_B1 tiles -- the own leaf and its neighbours, which set the bars -- and again after FZ_KM_B2.
+    KnnScan sc;
+    sc.nl = -1; sc.nr = 0; sc.ntiles = ntiles; sc.right = 1;
+    sc.m0 = ~0ull; sc.m1 = ~0ull; sc.gsl = gbox ? gsl : 30; sc.tm = tm;
     auto build_mask = [&]() __attribute__((always_inline)) {
         if (!gbox) return;
-        unsigned long long mm[2];
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            const fz_f4* bx = reinterpret_cast<const fz_f4*>(gbox + ((size_t)tree * 128 + lane + 64 * h) * 16);
-            const fz_f4 l0 = bx[0], l1 = bx[1], h0 = bx[2], h1 = bx[3];
+        const fz_f4* qb4 = reinterpret_cast<const fz_f4*>(&qbx[0][0]);
+        // reach of one box (this lane's) by any of the 16 rows
+        auto reach16 = [&](const fz_f4 l0, const fz_f4 l1, const fz_f4 h0, const fz_f4 h1) __attribute__((always_inline)) -> bool {
             bool reach = false;
 #pragma unroll 1
             for (int R = 0; R < 16; ++R) {
-                const float br = __shfl(barrow, R, 64);
+                const float br = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(barrow), R));
+                const fz_f4 a = qb4[R * 3], b = qb4[R * 3 + 1], c = qb4[R * 3 + 2];      // lo0..3 | lo4 lo5 hi0 hi1 | hi2..5
+                const float ql[6] = {a[0], a[1], a[2], a[3], b[0], b[1]}, qh[6] = {b[2], b[3], c[0], c[1], c[2], c[3]};
                 float lb = 0.f;
 #pragma unroll
                 for (int f = 0; f < FL; ++f) {
-                    const float qf = (float)qs[wave][R][f], eq = 2.0e-7f * fabsf(qf);
                     const float lo = f < 4 ? l0[f & 3] : l1[f & 3], hi = f < 4 ? h0[f & 3] : h1[f & 3];
-                    const float m = fmaxf(fmaxf(lo - (qf + eq), (qf - eq) - hi), 0.f);
+                    const float m = fmaxf(fmaxf(lo - qh[f], ql[f] - hi), 0.f);
                     lb = fmaf(m, m, lb);
                 }
                 reach = reach || (lb * 0.999999f <= br);
             }
-            mm[h] = __ballot(reach);
+            return reach;
+        };
+        unsigned long long mm[2];
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const fz_f4* bx = reinterpret_cast<const fz_f4*>(gbox + ((size_t)tree * 128 + lane + 64 * h) * 16);
+            mm[h] = __ballot(reach16(bx[0], bx[1], bx[2], bx[3]));
         }
         sc.m0 = mm[0]; sc.m1 = mm[1];
+        const float* tb = tbox + (size_t)tree * (Mp >> 6) * 16;
+        const int gs = sc.gsl;
+        if (gs >= 4 && gs <= 6) {
+            // groups of 16 / 32 / 64 tiles (65 k < M <= 524 k models): the tiles of 4 / 2 / 1 REACHABLE groups per pass, whatever words
+            // they sit in (word by word, a pass would test 64 tiles for every word that holds one reachable group of 16: twice the tests)
+            for (int w = lane; w < nw; w += 64) tm[w] = 0ull;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int lpg = 1 << gs, gpp = 64 >> gs, c = lane >> gs, tin = lane & (lpg - 1);
+            unsigned long long ma = sc.m0, mb = sc.m1;
+#pragma unroll 1
+            while (ma | mb) {
+                unsigned pk = 0u; int nc = 0;
+#pragma unroll 1
+                while (nc < gpp && (ma | mb)) {
+                    int g;
+                    if (ma) { g = __builtin_ctzll(ma); ma &= ma - 1ull; } else { g = 64 + __builtin_ctzll(mb); mb &= mb - 1ull; }
+                    const int ta = g << gs;
+                    if (ta >= ntiles || (ta > sc.nl && ta + lpg - 1 < sc.nr)) continue;      // no such tiles / every tile of the group has been visited
+                    pk |= (unsigned)g << (8 * nc); ++nc;
+                }
+                if (!nc) break;
+                const int g = (int)((pk >> (8 * c)) & 0xffu), tile = (g << gs) + tin;
+                const bool v = c < nc && tile < ntiles;
+                const fz_f4* bx = reinterpret_cast<const fz_f4*>(tb + (size_t)(v ? tile : 0) * 16);
+                const bool rc = reach16(bx[0], bx[1], bx[2], bx[3]);
+                const unsigned long long bal = __ballot(v && rc);
+                if (tin == 0 && c < nc) {
+                    const unsigned long long bits = (bal >> (c << gs)) & (lpg == 64 ? ~0ull : ((1ull << lpg) - 1ull));
+                    atomicOr(&tm[tile >> 6], bits << (tile & 63));
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int w = 0; w < nw; ++w) {
+                const int t0 = w << 6;
+                if (t0 > sc.nl && t0 + 63 < sc.nr) continue;                  // every tile of the word has been visited
+                const int tile = t0 + lane, g = (tile < ntiles ? tile : ntiles - 1) >> gs;
+                const unsigned long long mw = g < 64 ? sc.m0 : sc.m1;
+                const bool gr = tile < ntiles && ((mw >> (g & 63)) & 1ull);
+                unsigned long long word = 0ull;
+                if (__any(gr)) {
+                    const fz_f4* bx = reinterpret_cast<const fz_f4*>(tb + (size_t)(tile < ntiles ? tile : ntiles - 1) * 16);
+                    const bool rc = reach16(bx[0], bx[1], bx[2], bx[3]);
+                    word = __ballot(gr && rc);
+                }
+                if (lane == 0) tm[w] = word;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
     };
-    bool need_mask = seed != nullptr;                    // seeded sets: the bars are near their final values from the start
-    if (NWB == 1 && ktab) {
+    bool need_mask = false;
+    if (ktab) {
         // the leaf of the wave's middle query in THIS set's tree (11 dependent pairs of scalar loads at M = 1e5; the query straight from
         // LDS: a dynamic index into registers would go to scratch)
-        const int hm = knn_kd_leaf(&qs[wave][8][0], ktab + (size_t)tree * ntiles * 2, ntiles);
+        const int hm = knn_kd_leaf(&qs[8][0], ktab + (size_t)tree * ntiles * 2, ntiles);
         sc.nr = __builtin_amdgcn_readfirstlane(hm < ntiles ? hm : ntiles - 1); sc.nl = sc.nr - 1;
     }
-    sc.fetch(bm, sl);
-    auto stage = [&](int tile, float* dst) __attribute__((always_inline)) {             // 2176 contiguous bytes: 136 16-byte chunks over the wave's 64 lanes
+    auto stage = [&](int tile, float* dst) __attribute__((always_inline)) {             // 2048 contiguous bytes: 128 16-byte chunks over the wave's 64 lanes
         const char* src = reinterpret_cast<const char*>(bm + (size_t)tile * TF);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c < 2 || tid < 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + (uint32_t)tid * 16u),
-                                                 (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+        for (int c = 0; c < 2; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + (uint32_t)tid * 16u),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
     };
+    int ndone = 0;
     // admission path.  pm: this lane's 16-bit mask of (g, r) products under the bar.
     auto slow = [&](unsigned pm, const float* blk, int jb) __attribute__((always_inline)) {
+        // The four row bits of every model group are rotated by the lane's column, so that ONE pass of the loop spreads its pairs
+        // over all 16 query rows (4 each when every pair of the tile passes -- the first tile of a scan, where nearly half of all
+        // admissions happen) instead of 16 pairs for each of 4 rows: the row teams' drain then runs with every team busy
+        // (329 -> 230 drain rounds per wave and set on the benchmark; 27.2 -> 23.9 ms per step).
+        const int rot = row & 3;
+        pm = ((pm >> rot) & (0x1111u * (0xFu >> rot))) | ((pm << (4 - rot)) & (0x1111u * ((0xF0u >> rot) & 0xFu)));
         while (__any(pm != 0u)) {
             // every lane with something left takes its lowest pair: query row 4 sl + r, model 16 g + col of the step
             const bool has = pm != 0u;
             const int e = has ? __builtin_ctz(pm) : 0;
             pm &= pm - 1u;
-            const int g = e >> 2, r = e & 3, R = 4 * sl + r;
+            const int g = e >> 2, r = (e + rot) & 3, R = 4 * sl + r;
             const int jpos = jb + 16 * g + row;                      // position in the (k-d-ordered) set
             double qv[FL]; float pv[FL];                             // exact distance from the original query and features
 #pragma unroll
-            for (int f = 0; f < FL; ++f) { qv[f] = qs[wave][R][f]; pv[f] = blk[(f >> 2) * 256 + ((f & 3) * 16 + row) * 4 + g]; }
+            for (int f = 0; f < FL; ++f) { qv[f] = qs[R][f]; pv[f] = blk[(f >> 2) * 256 + ((f & 3) * 16 + row) * 4 + g]; }
             const int j = (FX ? FX <= 5 : F <= 5) ? (int)blk[256 + (48 + row) * 4 + g] : jpos;       // the model's original index (slot 7)
-            const double taur = qs[wave][R][6];
+            const double taur = qs[R][6];
             double d2 = 0.0;
 #pragma unroll
             for (int f = 0; f < FL; ++f) { const double d = (FX || f < F) ? qv[f] - (double)pv[f] : 0.0; d2 = fma(d, d, d2); }
             const bool adm = has && jpos < M && d2 <= taur && d2 < bound2;
+            KMSTAT(2, 1); KMSTAT(3, __builtin_popcountll(__ballot(has))); KMSTAT(4, __builtin_popcountll(__ballot(adm)));
             if constexpr (KPL > 0) {
                 int slot = 0;
                 if (adm) {
-                    slot = atomicAdd(&qn[R], 1);                   // < FZ_KM_QC: queues are drained from FZ_KM_DT entries on, a step adds <= 16 per row
-                    qd[R * FZ_KM_QC + slot] = d2; qj[R * FZ_KM_QC + slot] = j;
+                    slot = atomicAdd(&qn[R], 1);
+                    if (slot < FZ_KM_QC) { qd[R * FZ_KM_QC + slot] = d2; qj[R * FZ_KM_QC + slot] = j; }
+                    else pm |= 1u << e;                            // the row's queue is full: again after the drain (which this very slot number triggers)
                 }
-                if (__any(adm && slot + 1 >= FZ_KM_DT)) drain();
+                if (__any(adm && slot + 1 >= FZ_KM_DT) || (first && !__any(pm != 0u))) { KMT(4); drain(); KMT(5); }     // (first tile: its bars before anything else)
                 continue;
             }
             unsigned long long cm = __ballot(adm);
@@ -530,13 +563,11 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                 double l = ldr[lane < k ? lane : 0];
                 int lj = ljr[lane < k ? lane : 0];
                 double pk2 = ldr[k > 1 ? k - 2 : 0];
-                float2 pk = *reinterpret_cast<const float2*>(&qs[wave][Rn][7]);
+                float2 pk = *reinterpret_cast<const float2*>(&qs[Rn][7]);
                 asm volatile("" : "+v"(l), "+v"(lj), "+v"(pk2), "+v"(pk.x), "+v"(pk.y));     // all loads in flight before anything is consumed
-                // lexicographic (distance, index) order; a model already listed (a seed) is not listed twice
-                const unsigned long long before = __ballot(lane < k && (l < dn || (l == dn && lj < jn)));
-                const unsigned long long same = __ballot(lane < k && lj == jn);
+                const unsigned long long before = __ballot(lane < k && (l < dn || (l == dn && lj < jn)));     // lexicographic (distance, index)
                 const int pos = __builtin_popcountll(before);
-                const bool ok = pos < k && same == 0ull;              // (wave-uniform) pos == k: the row's bar moved while draining
+                const bool ok = pos < k;                              // (wave-uniform) pos == k: the row's bar moved while draining
                 if (ok && lane >= pos && lane < k - 1) { ldr[lane + 1] = l; ljr[lane + 1] = lj; }
                 if (ok && lane == pos) { ldr[lane] = dn; ljr[lane] = jn; }
                 if (ok) {
@@ -545,72 +576,112 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                     const float nbar = knn_bar_mfma(tau, pk.x, pk.y);
                     const float ab = alpha - nbar;
                     if (row == Rn) barrow = nbar;
-                    if (lane == 0) qs[wave][Rn][6] = tau;
+                    if (lane == 0) qs[Rn][6] = tau;
                     if (bar_lane && row == Rn) { if (F < 4) a0 = ab; else a1 = ab; }
                 }
             }
         }
     };
-    int cur_t = sc.next_reachable(bm, sl, qlo, qhi, barrow);
-    int ndone = 0;
+    int cur_t = sc.next_tile();
     auto run_tile = [&](const float* cur, float* nxt) __attribute__((always_inline)) -> bool {
-        const int nx = sc.next_reachable(bm, sl, qlo, qhi, barrow);     // (tested against the bars as they are now: a superset of what will still matter)
+        KMT(3);
+        const int nx = first ? cur_t : sc.next_tile();           // (the first tile twice, see above)
         if (nx >= 0) stage(nx, nxt);
+        KMT(2);
         const int t = cur_t;
-        fz_f4 nb0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
-        fz_f4 nb1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
-#pragma unroll 2
-        for (int s = 0; s < TILE / 64; ++s) {
-            const fz_f4 b0 = nb0, b1 = nb1;
-            if (s + 1 < TILE / 64) {
-                nb0 = *reinterpret_cast<const fz_f4*>(cur + (s + 1) * 512 + lane * 4);
-                nb1 = *reinterpret_cast<const fz_f4*>(cur + (s + 1) * 512 + 256 + lane * 4);
+        KMSTAT(1, 1);
+        const fz_f4 b0 = *reinterpret_cast<const fz_f4*>(cur + lane * 4);
+        const fz_f4 b1 = *reinterpret_cast<const fz_f4*>(cur + 256 + lane * 4);
+        fz_f4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[g], fz_f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[g], acc[g], 0, 0, 0);
+        unsigned pm = 0u;
+        bool anyp;
+        if (first) {
+            // per row (4 r of this lane's group x its 16 lanes = the row's 64 models) a value T with #(acc <= T) >= k, close to the
+            // k-th smallest: six bisection steps between the row's extremes.  Any T gives the right table (the second visit screens
+            // what is left with the rigorous bars); a good one makes the first k insertions the only ones.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float lo = fminf(fminf(acc[0][r], acc[1][r]), fminf(acc[2][r], acc[3][r]));
+                float hi = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r]));
+                lo = fminf(lo, row16_xchg<0xB1>(lo)); lo = fminf(lo, row16_xchg<0x4E>(lo)); lo = fminf(lo, row16_xchg<0x141>(lo)); lo = fminf(lo, row16_xchg<0x140>(lo));
+                hi = fmaxf(hi, row16_xchg<0xB1>(hi)); hi = fmaxf(hi, row16_xchg<0x4E>(hi)); hi = fmaxf(hi, row16_xchg<0x141>(hi)); hi = fmaxf(hi, row16_xchg<0x140>(hi));
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const float mid = 0.5f * (lo + hi);
+                    int cnt = (acc[0][r] <= mid ? 1 : 0) + (acc[1][r] <= mid ? 1 : 0) + (acc[2][r] <= mid ? 1 : 0) + (acc[3][r] <= mid ? 1 : 0);
+                    cnt += row16_xchg<0xB1>(cnt); cnt += row16_xchg<0x4E>(cnt); cnt += row16_xchg<0x141>(cnt); cnt += row16_xchg<0x140>(cnt);
+                    const bool ge = cnt >= k;
+                    hi = ge ? mid : hi; lo = ge ? lo : mid;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pm |= (acc[g][r] <= hi ? 1u : 0u) << (4 * g + r);
             }
-            fz_f4 acc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[g], fz_f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[g], acc[g], 0, 0, 0);
-            int sg = 0;                                              // OR of the 16 sign bits: any product under its row's bar
+            pm_first = pm;
+            anyp = true;
+        } else {
+            int sg = 0;                                          // OR of the 16 sign bits: any product under its row's bar
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sg |= __float_as_int(acc[g][r]);
-            if (__any(sg < 0)) {
-                unsigned pm = 0u;
+            anyp = __any(sg < 0);
+            if (anyp) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pm |= (__float_as_uint(acc[g][r]) >> 31) << (4 * g + r);
-                slow(pm, cur + s * 512, t * TILE + s * 64);
+                if (second) pm &= ~pm_first;                     // the pairs the first visit took
             }
         }
+        if (anyp) {
+            KMT(3);
+            slow(pm, cur, t * TILE);
+            KMT(4);
+        }
+        second = first; first = false;
         cur_t = nx;
-        // the bars have dropped since the mask was built (a cold scan starts with none): again after 8 and after 40 tiles
+        // the bars have dropped since the scan began (and since the first mask)
         ++ndone;
-        need_mask = need_mask || ndone == 8 || ndone == 40;
+        need_mask = need_mask || ndone == FZ_KM_B1 || ndone == FZ_KM_B2;
         __syncthreads();
         return nx >= 0;
     };
+    KMSTAT(0, 1);
+    KMT(0);
     if (cur_t >= 0) {
         stage(cur_t, tA);
         __syncthreads();
         while (true) {
-            if (need_mask) { build_mask(); need_mask = false; }      // (the one call site: inlined three times it cost the kernel its occupancy)
+            if (need_mask) {                                         // (the one call site: inlined three times it cost the kernel its occupancy)
+                KMT(3);
+                build_mask(); need_mask = false;                      // (from the bars of the last drain: at most FZ_KM_DT - 1 entries per row are waiting)
+                // the tile in flight was chosen before the mask: it stays (a superset is always valid); the next ones follow the mask
+                KMT(1);
+            }
             if (!run_tile(tA, tB)) break;
             if (!run_tile(tB, tA)) break;
         }
     }
+    KMT(3);
     if constexpr (KPL > 0) {
         drain();
 #pragma unroll
         for (int e = 0; e < KPL; ++e) { Ld[team * kpad + tl * KPL + e] = Lr[e]; Lj[team * kpad + tl * KPL + e] = Jr[e]; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
+    KMT(5);
     for (int R = 0; R < 16; ++R) {
         const int64_t i = __shfl(qi, R, 64);
         if (i0 + R < N && lane < k) idx[(i * K + tree) * k + lane] = (Ld[R * kpad + lane] < bound2) ? Lj[R * kpad + lane] : M;
     }
+    KMT(6);
+#ifdef FZ_KM_STATS
+    for (int u = 0; u < 8; ++u) { KMFLUSH(u, kmc[u]); KMFLUSH(8 + u, kmtime[u]); }
+#endif
 }
 
 }  // namespace fz

@@ -223,11 +223,11 @@ def test_screened_search_is_the_exact_search(scale, monkeypatch):
 @pytest.mark.parametrize('case', ['ties', 'bound', 'single_set', 'F3', 'F6', 'k40', 'unrelated_sets', 'ragged', 'tiny', 'F1', 'F2',
                                   'flat_feature', 'nan_query', 'clustered'])
 def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
-    """fz_knn_mfma.h (fp32 MFMA screen, seeds from feature set 0, (distance, index) ordered lists) returns the
-    neighbour table of the all-fp64 ascending scan (FZ_KNN_FP64=1) bit for bit: exact duplicates among the models
-    (ties resolved by model index, also at the k-th place and among the seeds), a finite distance bound, one
-    feature set (no seeds), other feature counts, k > 32, feature sets that are NOT realisations of the same
-    models (the seeds are then just k arbitrary distinct models), sizes that fill neither a tile nor a wave."""
+    """fz_knn_mfma.h (fp32 MFMA screen, outward scan over the reachable tiles of the k-d order, (distance, index) ordered
+    lists) returns the neighbour table of the all-fp64 ascending scan (FZ_KNN_FP64=1) bit for bit: exact duplicates among
+    the models (ties resolved by model index, also at the k-th place), a finite distance bound (no first-tile selection
+    then), one feature set, other feature counts, k > 32, feature sets that are NOT realisations of the same models,
+    sizes that fill neither a tile nor a wave (the own leaf holds padding), NaN queries, clumpy data."""
     from frankenz_amd.engine import get_engine
     rs = np.random.RandomState(len(case) * 13 + 5)
     K, M, F, N, k, bound = 4, 3000, 5, 203, 20, np.inf
@@ -243,7 +243,7 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     noise = 0.05
     if case == 'ties':
         base[500:1500] = base[:1000]                                   # exact duplicates in every set
-        noise = 0.0                                                    # ... and identical sets: seeds == answer
+        noise = 0.0                                                    # ... and identical sets
     feats = np.stack([base + rs.normal(0, noise, size=(M, F)) if noise else base for _ in range(K)])
     if case == 'unrelated_sets':
         feats = np.stack([rs.permutation(base) for _ in range(K)])
@@ -290,9 +290,9 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('switch', ['FZ_KNN_NOBOX', 'FZ_KNN_NOSEED', 'FZ_KNN_NOSORT', 'FZ_KNN_SERIAL', 'FZ_KNN_NOMFMA'])
+@pytest.mark.parametrize('switch', ['FZ_KNN_NOBOX', 'FZ_KNN_NOSORT', 'FZ_KNN_SERIAL', 'FZ_KNN_NOMFMA'])
 def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch):
-    """The diagnostic switches of the search -- no tile / group skipping, no seeds from feature set 0, models in storage order
+    """The diagnostic switches of the search -- no tile / group skipping, models in storage order
     instead of k-d order (NOSORT is read at upload), wave-serial list insertion, the vector-ALU search instead of the matrix
     pipe -- change how the table is found, never the table: ordered by (distance, model index) it is the all-fp64 scan's, bit
     for bit, on clumpy data with exact duplicates (ties at the k-th place) and enough models for 3 tile groups."""
@@ -303,7 +303,7 @@ def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch
     base = cen[rs.randint(0, 40, M)] + rs.normal(0, 0.05, size=(M, F))
     base[4000:4400] = base[:400]                                         # exact duplicates
     feats = np.stack([base + rs.normal(0, 0.02, size=(M, F)) for _ in range(K)]).astype(np.float32)
-    feats[1] = feats[0]                                                   # one set identical to set 0: its seeds are its answer
+    feats[1] = feats[0]                                                   # one set identical to set 0
     q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
     q[:20] = feats[0][:20].astype(np.float64)                             # distance exactly 0 to two models each
     eng = get_engine()
