@@ -304,10 +304,9 @@ int FZ_NAME(fz_knnsubset_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_
     FZCHK(c->d_kv.ensure(sizeof(KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(KdeView), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int wcap = fz_knn_wcap(W);
-    const size_t per_wave = (size_t)kv.acc_stride + wcap + (size_t)(wcap + 4 * wcap) / 2;      // row | lnl | list, hash keys, hash positions (fz_knn.h)
+    const size_t per_wave = fz_knn_subset_lds_doubles(kv.acc_stride, W);      // list | hash table, then ln-likelihoods + accumulation row (fz_knn.h)
     int wpb = 4;
-    while (wpb > 1 && per_wave * 8 * wpb > 80 * 1024) wpb >>= 1;
+    while (wpb > 1 && per_wave * 8 * wpb > 53 * 1024) wpb >>= 1;             // (three blocks per CU)
     const size_t lds = per_wave * 8 * wpb;
     if (lds > 160 * 1024) return fail(-5, "k-NN PDF grid too large for LDS");
     Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);

@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) void k_knn_query32(const float* __restrict__ f
 // capacities per launch: wcap = K*k rounded up to a power of two (>= 64), hash table of 2 wcap slots (open addressing)
 #define FZ_KNN_WMAX 4096          // largest K*k handled (k <= 64 per set, any K up to 64: the reference takes any; knn.py:190-193)
 __host__ __device__ inline int fz_knn_wcap(int W) { int c = 64; while (c < W) c <<= 1; return c; }
+// doubles of LDS per wave of k_knn_subset: the list, then max(hash table, ln-likelihoods + accumulation row)
+__host__ __device__ inline size_t fz_knn_subset_lds_doubles(int acc_stride, int W) {
+    const size_t wcap = (size_t)fz_knn_wcap(W), a = 2 * wcap, b = wcap + (size_t)acc_stride;
+    return wcap / 2 + (a > b ? a : b);
+}
 
 struct KnnOut {                    // padded outputs of knn.py:812-821 (any may be NULL)
     int64_t* neighbors;            // (N,W) -99 padded
@@ -213,7 +218,10 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
                                                     int64_t N, int M, const int64_t* __restrict__ idx, int W,
                                                     int free_scale, double wt_thresh, int normalize, KnnOut out,
                                                     int* __restrict__ errflag) {
-    // LDS per wave (doubles): row[acc_stride] | lnl[wcap] | then ints: list[wcap], key[2 wcap], pos[2 wcap]
+    // LDS per wave: list[wcap] ints, then ONE region that first holds the de-dup hash table (key[2 wcap], pos[2 wcap] ints) and, once
+    // the list is made, the ln-likelihoods lnl[wcap] and the accumulation row[acc_stride] (doubles): 11.8 KB instead of 20 KB at
+    // K k = 500 on a 701-point grid -- the kernel waits on gathers 2/3 of its time and LDS bounds its occupancy
+    // (fz_knn_subset_lds_doubles sizes the launch)
     extern __shared__ double smem[];
     PH ph = ph_;
     ph.tb = global_tabs();
@@ -222,11 +230,11 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= N) return;
     const int wcap = fz_knn_wcap(W), hcap = 2 * wcap, hshift = 32 - (31 - __builtin_clz(hcap));
-    const size_t per_wave = (size_t)acc_stride + wcap + (size_t)(wcap + 2 * hcap) / 2;
-    double* row = smem + wave * per_wave;
-    double* lnls = row + acc_stride;
-    int* list = reinterpret_cast<int*>(lnls + wcap);
-    int* hkey = list + wcap;
+    const size_t per_wave = fz_knn_subset_lds_doubles(acc_stride, W);
+    int* list = reinterpret_cast<int*>(smem + wave * per_wave);
+    double* lnls = smem + wave * per_wave + wcap / 2;
+    double* row = lnls + wcap;
+    int* hkey = reinterpret_cast<int*>(lnls);
     int* hpos = hkey + hcap;
     const KdeView kv = *kvp;
 

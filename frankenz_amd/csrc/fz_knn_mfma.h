@@ -212,6 +212,7 @@ struct KnnScan {
     unsigned long long m0, m1;                             // reachable groups of 2^gsl tiles (bit g; wave-uniform), see k_knn_maskboxes
     int gsl;
     const unsigned long long* tm;                          // LDS: bit t & 63 of word t >> 6 = tile t may hold a model under some row's bar
+    // (the word of a scan head is read from LDS at every step: keeping the two current words in scalar registers measured 15.85 against 15.45 ms)
     __device__ __forceinline__ int next_tile() {
         while (true) {
             if (nr >= ntiles && nl < 0) return -1;
@@ -259,8 +260,8 @@ struct KnnScan {
 #endif
 // dynamic LDS: the lists / queues, then one bit per tile (fz_knn_host.inc sizes the launch with the same expression)
 __host__ __device__ inline size_t knn_mfma_list_bytes(int kpad, int kpl) {
-    const size_t a = (size_t)16 * kpad * 12, b = kpl ? (size_t)16 * FZ_KM_QC * 12 : (size_t)0;
-    return ((a > b ? a : b) + 15) & ~(size_t)15;
+    // register lists (kpl > 0): only the rows' admission queues live in LDS; else the sorted lists themselves
+    return ((kpl ? (size_t)16 * FZ_KM_QC * 12 : (size_t)16 * kpad * 12) + 15) & ~(size_t)15;
 }
 template <int TILE, int FX, int NWB, int KPL>
 static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __restrict__ bmat, const float* __restrict__ cen,
@@ -279,8 +280,8 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     __shared__ __attribute__((aligned(16))) float qbx[16][12];   // the queries in fp32 with their rounding: lo[6] | hi[6] (tile tests)
     __shared__ int qn[16];                              // KPL: entries waiting in each row's queue
     extern __shared__ double s_lists[];
-    // KPL: the per-row queues of admitted (distance, model) pairs reuse the lists' LDS -- the lists are only there
-    // when the result is written; in between they live in registers
+    // KPL: the per-row queues of admitted (distance, model) pairs take the place of the lists, which live in registers from the
+    // first tile to the output
     double* qd = s_lists;                                // [16][FZ_KM_QC]
     int* qj = reinterpret_cast<int*>(s_lists + 16 * FZ_KM_QC);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -296,7 +297,7 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     double* Ld = s_lists;                                                                // [16][kpad]
     int* Lj = reinterpret_cast<int*>(s_lists + (size_t)16 * kpad);
     unsigned long long* tm = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_lists) + knn_mfma_list_bytes(kpad, KPL));
-    for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
+    if constexpr (KPL == 0) for (int e = lane; e < 16 * kpad; e += 64) { Ld[e] = INFINITY; Lj[e] = M + e % kpad; }
     for (int w = lane; w < nw; w += 64) tm[w] = (w + 1 < nw || (ntiles & 63) == 0) ? ~0ull : ((1ull << (ntiles & 63)) - 1ull);     // every tile, until the first build
     if (lane < 16) qn[lane] = 0;
     // ---- the wave's 16 queries: fp64 copies in LDS, A operands in registers ----
@@ -647,7 +648,9 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         // the bars have dropped since the scan began (and since the first mask)
         ++ndone;
         need_mask = need_mask || ndone == FZ_KM_B1 || ndone == FZ_KM_B2;
+        KMT(3);
         __syncthreads();
+        KMT(7);
         return nx >= 0;
     };
     KMSTAT(0, 1);
@@ -669,14 +672,19 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
     KMT(3);
     if constexpr (KPL > 0) {
         drain();
+        KMT(5);
+        const int64_t i = __shfl(qi, team, 64);                     // the team's row (lanes 0..15 hold rows 0..15)
+        if (i0 + team < N) {
 #pragma unroll
-        for (int e = 0; e < KPL; ++e) { Ld[team * kpad + tl * KPL + e] = Lr[e]; Lj[team * kpad + tl * KPL + e] = Jr[e]; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
-    KMT(5);
-    for (int R = 0; R < 16; ++R) {
-        const int64_t i = __shfl(qi, R, 64);
-        if (i0 + R < N && lane < k) idx[(i * K + tree) * k + lane] = (Ld[R * kpad + lane] < bound2) ? Lj[R * kpad + lane] : M;
+            for (int e = 0; e < KPL; ++e)
+                if (tl * KPL + e < k) idx[(i * K + tree) * k + tl * KPL + e] = (Lr[e] < bound2) ? Jr[e] : M;
+        }
+    } else {
+        KMT(5);
+        for (int R = 0; R < 16; ++R) {
+            const int64_t i = __shfl(qi, R, 64);
+            if (i0 + R < N && lane < k) idx[(i * K + tree) * k + lane] = (Ld[R * kpad + lane] < bound2) ? Lj[R * kpad + lane] : M;
+        }
     }
     KMT(6);
 #ifdef FZ_KM_STATS
