@@ -290,6 +290,43 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,bound', [(40000, np.inf), (200000, np.inf), (400000, np.inf), (600000, np.inf), (200000, 0.3), (600000, 0.2)])
+def test_reachability_mask_at_every_group_size(M, bound, monkeypatch):
+    """The scan's bit mask of reachable tiles (fz_knn_mfma.h, build_mask) is built along three routes by the size of the tile groups:
+    word by word under the group mask (groups of 1-8 tiles, M <= 65 k: 40 000 here; and groups of 128+ tiles, M > 524 k: 600 000),
+    and 4 / 2 / 1 reachable groups of 16 / 32 / 64 tiles per pass (1e5 in test_config4..., 200 000 and 400 000 here).  Clumpy data
+    (most tiles beyond every bar), queries in and between the clumps, with and without a distance bound (a bounded search takes
+    no first-tile selection): the table must be the all-fp64 scan's, bit for bit, and the host's own stable argsort on a sample."""
+    from frankenz_amd.engine import get_engine
+    rs = np.random.RandomState(M // 1000 + (0 if np.isinf(bound) else 7))
+    K, F, N, k = 2, 5, 96, 20
+    cen = rs.normal(22.0, 2.0, size=(60, F))
+    base = cen[rs.randint(0, 60, M)] + rs.normal(0, 0.08, size=(M, F))
+    base[1000:1200] = base[:200]                                          # exact duplicates
+    feats = np.stack([base + rs.normal(0, 0.02, size=(M, F)) for _ in range(K)]).astype(np.float32)
+    q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
+    q[N // 2:] = 0.5 * (cen[rs.randint(0, 60, N - N // 2)] + cen[rs.randint(0, 60, N - N // 2)])      # between two clumps: wide balls
+    eng = get_engine()
+    eng.upload_models(np.ones((M, F)), np.zeros((M, F)), np.ones((M, F)))
+    eng.knn_upload_trees(feats)
+    out = {}
+    for name in ('mfma', 'fp64'):
+        with monkeypatch.context() as mp:
+            if name == 'fp64':
+                mp.setenv('FZ_KNN_FP64', '1')
+            idx = np.empty((N, K * k), dtype=np.int64)
+            eng.knn_query(np.ascontiguousarray(q), k, bound, idx)
+            out[name] = idx
+    np.testing.assert_array_equal(out['mfma'], out['fp64'])
+    for i in (0, N // 2 - 1, N // 2, N - 1):
+        for t in range(K):
+            d2 = ((q[i][None, :] - feats[t].astype(np.float64)) ** 2).sum(axis=1)
+            want = np.argsort(d2, kind='stable')[:k]
+            want = np.where(d2[want] < bound ** 2, want, M)
+            np.testing.assert_array_equal(out['mfma'][i, t * k:(t + 1) * k], want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('switch', ['FZ_KNN_NOBOX', 'FZ_KNN_NOSORT', 'FZ_KNN_SERIAL', 'FZ_KNN_NOMFMA'])
 def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch):
     """The diagnostic switches of the search -- no tile / group skipping, models in storage order
