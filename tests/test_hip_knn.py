@@ -221,7 +221,7 @@ def test_screened_search_is_the_exact_search(scale, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['ties', 'bound', 'single_set', 'F3', 'F6', 'k40', 'unrelated_sets', 'ragged', 'tiny', 'F1', 'F2',
-                                  'flat_feature', 'nan_query', 'clustered'])
+                                  'flat_feature', 'nan_query', 'clustered', 'k1', 'k7', 'k25', 'k32', 'k32_ties', 'few_models'])
 def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     """fz_knn_mfma.h (fp32 MFMA screen, outward scan over the reachable tiles of the k-d order, (distance, index) ordered
     lists) returns the neighbour table of the all-fp64 ascending scan (FZ_KNN_FP64=1) bit for bit: exact duplicates among
@@ -234,14 +234,19 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     if case == 'single_set': K = 1
     if case == 'F3': F = 3
     if case == 'F6': F = 6
-    if case == 'k40': k = 40
+    if case == 'k40': k = 40                                            # wave-serial LDS lists
+    if case == 'k1': k = 1
+    if case == 'k7': k = 7                                              # register lists of 4 x 5, partly filled
+    if case == 'k25': k = 25                                            # register lists of 4 x 8
+    if case in ('k32', 'k32_ties'): k = 32
+    if case == 'few_models': M, k = 25, 20                              # one tile, mostly padding: fewer than k under any bar of the first-tile selection
     if case == 'ragged': M, N = 1000 + 37, 17
     if case == 'tiny': M, N, k = 10, 3, 4
     if case == 'F1': F = 1
     if case == 'F2': F = 2
     base = rs.normal(22.0, 1.0, size=(M, F))
     noise = 0.05
-    if case == 'ties':
+    if case in ('ties', 'k32_ties'):
         base[500:1500] = base[:1000]                                   # exact duplicates in every set
         noise = 0.0                                                    # ... and identical sets
     feats = np.stack([base + rs.normal(0, noise, size=(M, F)) if noise else base for _ in range(K)])
@@ -257,7 +262,7 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
     q = base[rs.choice(M, N)] + rs.normal(0, 0.05, size=(N, F))
     if case == 'nan_query':
         q[3, 1] = np.nan; q[100] = np.inf
-    if case == 'ties':
+    if case in ('ties', 'k32_ties'):
         q[:50] = feats[0][rs.choice(1000, 50)].astype(np.float64)        # distance exactly 0 to two models each
     if case == 'bound':
         bound = 0.25
@@ -282,7 +287,7 @@ def test_matrix_pipe_search_is_the_exact_search(case, monkeypatch):
             want = np.argsort(d2, kind='stable')[:k]
             want = np.where(d2[want] < bound ** 2, want, M)
             got = out['mfma'][i, t * k:(t + 1) * k]
-            if case == 'ties':
+            if case in ('ties', 'k32_ties'):
                 np.testing.assert_array_equal(got, want)
             else:
                 np.testing.assert_array_equal(np.sort(d2[got[got < M]]), np.sort(d2[want[want < M]]))
