@@ -119,17 +119,9 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
     __device__ __forceinline__ double2 tile_chunk(int64_t tile, int ch) const {
         return *reinterpret_cast<const double2*>(tile_chunk_ptr<TL>(tile, ch));
     }
-    // record j of the array-of-records copy, j wave-uniform: scalar loads -> SGPR operands (k_ol)
-    __device__ __forceinline__ void load_model_rec(int64_t j, typename P::MR& m) const {
-        const double* r = ((MODE == 0) ? P::mv.rec0 : P::mv.rec1) + j * RW;
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            m.y[b] = r[b];
-            if (MODE == 0) m.ye2[b] = r[BT + b];
-        }
-        m.bits = 0xffffffffu;
-    }
-    // the same record for a per-lane j, as 16-byte loads (records are 16-B aligned: RW is even)
+    // model j from the array-of-records copy, per-lane j, as 16-byte loads (records are 16-B aligned: RW is even): one or two
+    // cache lines per model instead of BT (2 BT in mode A) -- for GATHERS (k_knn_subset: 500 scattered models per object; the
+    // [band][model] arrays moved 320 KB of cache lines per object, the records move 64 KB)
     __device__ __forceinline__ void load_model_rec16(int64_t j, typename P::MR& m) const {
         const double2* r = reinterpret_cast<const double2*>(((MODE == 0) ? P::mv.rec0 : P::mv.rec1) + j * RW);
         double v[RW];
@@ -140,7 +132,7 @@ struct PhotSrc : Phot<BT, MODE, VAR> {
             m.y[b] = v[b];
             if (MODE == 0) m.ye2[b] = v[BT + b];
         }
-        m.bits = 0xffffffffu;
+        m.bits = P::MASKED ? P::mv.bits[j] : 0xffffffffu;
     }
     template <int TL = TILE>
     __device__ __forceinline__ void load_model_lds(const double* t, int k, typename P::MR& m) const {

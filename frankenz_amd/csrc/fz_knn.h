@@ -242,28 +242,22 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
     for (int s = lane; s < hcap; s += 64) { hkey[s] = -1; hpos[s] = 0x7fffffff; }
     const int64_t* myrow = idx + i * W;
     bool bad = false;
-    for (int p0 = 0; p0 < W; p0 += 64) {
-        const int p = p0 + lane;
-        if (p < W) {
-            const long long v = myrow[p];
-            if (v < 0 || v >= M) bad = true;          // KDTree's "missing" index: models[M] raises in the reference
-            const int key = (int)v;
-            unsigned h = ((unsigned)key * 2654435761u) >> hshift;          // log2(hcap) bits
-            while (true) {
-                const int prev = atomicCAS(&hkey[h], -1, key);
-                if (prev == -1 || prev == key) break;
-                h = (h + 1) & (hcap - 1);
-            }
-            atomicMin(&hpos[h], p);
+    auto put = [&](int p, long long v) __attribute__((always_inline)) {       // p < W
+        if (v < 0 || v >= M) bad = true;              // KDTree's "missing" index: models[M] raises in the reference
+        const int key = (int)v;
+        unsigned h = ((unsigned)key * 2654435761u) >> hshift;          // log2(hcap) bits
+        while (true) {
+            const int prev = atomicCAS(&hkey[h], -1, key);
+            if (prev == -1 || prev == key) break;
+            h = (h + 1) & (hcap - 1);
         }
-    }
-    if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+        atomicMin(&hpos[h], p);
+    };
     int nn = 0;                                        // wave-uniform running count
-    for (int p0 = 0; p0 < W; p0 += 64) {
-        const int p = p0 + lane;
+    auto take = [&](int p, long long v) __attribute__((always_inline)) {      // every lane of the wave; p >= W: no entry
         bool first = false; int key = 0;
         if (p < W) {
-            key = (int)myrow[p];
+            key = (int)v;
             unsigned h = ((unsigned)key * 2654435761u) >> hshift;
             while (hkey[h] != key) h = (h + 1) & (hcap - 1);
             first = (hpos[h] == p);
@@ -272,6 +266,20 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
         if (first) list[nn + pre] = key;
         nn += __builtin_popcountll(mask);
+    };
+    if (W <= 512) {                                    // the whole row in registers: ONE gather latency instead of one per 64 entries, twice
+        long long vr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vr[u] = (u * 64 + lane < W) ? myrow[u * 64 + lane] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u * 64 + lane < W) put(u * 64 + lane, vr[u]);
+        if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u * 64 < W) take(u * 64 + lane, vr[u]);
+    } else {
+        for (int p0 = 0; p0 < W; p0 += 64) if (p0 + lane < W) put(p0 + lane, myrow[p0 + lane]);
+        if (__any(bad)) { if (lane == 0) atomicExch(errflag, 1); return; }
+        for (int p0 = 0; p0 < W; p0 += 64) take(p0 + lane, p0 + lane < W ? myrow[p0 + lane] : 0);
     }
     if (out.nnbr && lane == 0) out.nnbr[i] = nn;
     if (out.neighbors) for (int s = lane; s < W; s += 64) out.neighbors[i * W + s] = s < nn ? list[s] : -99;
@@ -281,12 +289,14 @@ __global__ __launch_bounds__(256) void k_knn_subset(PH ph_, const KdeView* __res
     ph.load_obj(i, ob);
     MS st; ms_init(st);
     bool isnan0 = false, anynan = false;
+    // (records, and the next 64 models' requested before this round's are evaluated: the kernel waits on these gathers)
+    typename PH::MR mnext;
+    ph.load_model_rec16(lane < nn ? list[lane] : 0, mnext);
     for (int s0 = 0; s0 < W; s0 += 64) {
         const int s = s0 + lane;
         const bool in = s < nn;
-        const int j = in ? list[s] : 0;
-        typename PH::MR m;
-        ph.load_model(j, m);
+        const typename PH::MR m = mnext;
+        if (s0 + 64 < W) ph.load_model_rec16(s + 64 < nn ? list[s + 64] : 0, mnext);
         const PairOut r = ph.eval(ob, m);
         const double l = in ? r.lnl : -INFINITY;
         if (s < W) {
