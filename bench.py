@@ -413,11 +413,32 @@ def main():
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                            "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))
         else:
+            # what the search kernel did per wave (16 queries x one feature set): counters of THIS build at THIS shape, kept by
+            # tools/pmc_knn.sh in profiles/ (separate PMC passes; nothing is counted inside the timed region)
+            sprof = None
+            try:
+                cnt = {}
+                for ln in open(os.path.join(ROOT, "profiles", "r4_v2_pmc_knn.txt")):
+                    f = ln.split()
+                    if ln.startswith("k_knn_mfma") and "per_launch=" in ln:
+                        cnt[[w for w in f if w.startswith("SQ_")][0]] = float(ln.split("per_launch=")[1].split()[0])
+                wv = cnt["SQ_WAVES"]
+                import csv
+                kns = [float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_v2_kernel_stats_knn.csv")))
+                       if "k_knn_mfma" in r["Name"]][0]
+                simd_cycles = kns * 1e-9 * 2.4e9 * 256 * 4            # 256 CUs x 4 SIMDs at 2.4 GHz over the kernel's duration
+                sprof = {"source": "profiles/r4_v2_pmc_knn.txt + r4_v2_kernel_stats_knn.csv (1e5 objects x 25 sets x 1e5 models, k = 20)",
+                         "tiles_multiplied_per_wave": cnt["SQ_INSTS_MFMA"] / wv / 8.0, "tiles_per_set": (100000 + 63) // 64,
+                         "valu_insts_per_wave": cnt["SQ_INSTS_VALU"] / wv, "salu_insts_per_wave": cnt["SQ_INSTS_SALU"] / wv,
+                         "mfma_busy_frac": cnt["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,            # (counted in cycles)
+                         "valu_busy_frac": cnt["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles}           # (counted in units of 4 cycles)
+            except Exception:
+                pass
             print(json.dumps({"metric": "KMCkNN objects/sec (K=25 exact top-20 searches + subset PDFs)",
                               "value": N_total * args.steps / dt, "unit": "objects/s",
                               "search_evals_per_s": 25.0 * N_total * M * args.steps / dt, "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                              "kernel_ms_per_step": tm["ms_knn"] / args.steps, "pdfs_normalised": ok,
+                              "kernel_ms_per_step": tm["ms_knn"] / args.steps, "pdfs_normalised": ok, "search_profile": sprof,
                               "dtype": "f64 (fp32 MFMA screen of the search, every admitted distance re-checked in fp64)", "data": "synthetic",
                               "scaling": "strong" if (strong or world == 1) else "weak",
                               "ms_compute": (split[0] / args.steps * 1e3) if do_gather else None,
