@@ -12,11 +12,13 @@
 // beta and keeps the big |q|^2 + |p|^2 - 2 q.p cancellation out of the fp32 chain.
 // The product is only the SCREEN: the bar is provably above the exact k-th distance (bound below), and the
 // pairs under it recompute their distance in fp64 from the original query and features and enter the
-// query's sorted list (LDS, ordered by (distance, original index)) -- the neighbour table is the exact fp64
-// top-k, bit for bit, whatever the visiting order (tests/test_hip_knn.py
-// test_matrix_pipe_search_is_the_exact_search, tests/test_hip_fullsize.py at M = 1e5, K = 25, k = 20).
-// Around that: seeds from feature set 0, models in k-d order (tiles = leaves) and queries grouped by leaf with an outward scan from the
-// queries' own place, and tiles / groups of tiles skipped by bounding box (comments at k_knn_mfma).
+// query's sorted list (registers of a 4-lane team, ordered by (distance, original index)) -- the neighbour table is the
+// exact fp64 top-k, bit for bit, whatever the visiting order (tests/test_hip_knn.py
+// test_matrix_pipe_search_is_the_exact_search, test_reachability_mask_at_every_group_size, tests/test_hip_fullsize.py at M = 1e5,
+// K = 25, k = 20).
+// Around that: models in k-d order (tiles = leaves) and queries grouped by leaf, an outward scan from the queries' own leaf, that
+// leaf entered through its k nearest, and a bit mask of the tiles whose bounding box some query's bar still reaches (comments at
+// k_knn_mfma).  DESIGN.md 3.5 has the measurements each of these was chosen by.
 //
 // Bar.  u = 2^-24, Q = |q'|, P = max_p |p - c|, C = |c|.  Without rounding the product is
 // |q' - (p - c)|^2 - bar + e_a (alpha - bar) + e_b beta (|e| <= u), and | |q' - (p - c)| - |q - p| | <= u Q; the
