@@ -614,7 +614,7 @@ static int run_cdf(fz_ctx* c, int64_t n, int L, int64_t M, const double* rows, c
     if (rc) return rc;
     FZCHK(c->d_kv.ensure(sizeof(KdeView)));
     FZCHK(copy_in(c, c->d_kv.p, &kv, sizeof(KdeView)));
-    const size_t per_wave = ((size_t)kv.acc_stride + FZ_CDF_MAXK / 2) * 8;
+    const size_t per_wave = (size_t)kv.acc_stride * 8;
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
     const size_t lds = per_wave * wpb;
@@ -630,7 +630,6 @@ static int run_cdf(fz_ctx* c, int64_t n, int L, int64_t M, const double* rows, c
     HIPCHK(hipGetLastError());
     int ef = 0;
     FZCHK(copy_out(c, &ef, c->d_flags.p, sizeof ef));
-    if (ef == 2) return fail(-5, "CDF thresholding would drop more than %d kernels per object (cdf_thresh * Nmodel too large)", FZ_CDF_MAXK);
     if (ef) return fail(-3, "neighbour table entry outside [0, Nmodel) or Nneighbors outside [0, K*k]");
     return 0;
 }

@@ -8,6 +8,10 @@
 // cdf_thresh of the total (K >= 1; K <= cdf_thresh * Ny + 1).  That is a reference quirk
 // (it drops the most probable models), reproduced here as it is: find the top-K by
 // repeated arg-max (K is 1 for any peaked posterior), stack everything else unthresholded.
+// The arg-max walks the row in the strict order (weight descending, column ascending): the
+// last (weight, column) taken IS the exclusion set -- everything at or before it in that
+// order -- so K is unbounded and no list is kept (a flat posterior over 1e6 models at the
+// default cdf_thresh drops 200 of them; K rounds of one pass over the row each).
 // One object per wave, rows of ln-weights or linear weights read from a plane; optional
 // neighbour-table indirection for the k-NN variant.
 #pragma once
@@ -15,22 +19,19 @@
 
 namespace fz {
 
-#define FZ_CDF_MAXK 64
-
 static __global__ __launch_bounds__(256) void k_kde_cdf(const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int L,
                                                  int M, const double* __restrict__ rows,
                                                  const int64_t* __restrict__ nbr, const int64_t* __restrict__ nnb,
                                                  int is_log, double cdf_thresh, int normalize,
                                                  double* __restrict__ pdfs, double* __restrict__ lmap,
                                                  double* __restrict__ levid, int* __restrict__ errflag) {
-    extern __shared__ double smem[];                 // per wave: row[acc_stride] | excl[FZ_CDF_MAXK] ints
+    extern __shared__ double smem[];                 // per wave: row[acc_stride]
     const FastTabs tb = global_tabs();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= N) return;
-    double* row = smem + (size_t)wave * (acc_stride + FZ_CDF_MAXK / 2);
-    int* excl = reinterpret_cast<int*>(row + acc_stride);
+    double* row = smem + (size_t)wave * acc_stride;
     const KdeView kv = *kvp;
     const double* in = rows + i * (int64_t)L;
     const int n = nnb ? (int)nnb[i] : L;
@@ -66,6 +67,7 @@ static __global__ __launch_bounds__(256) void k_kde_cdf(const KdeView* __restric
     // ---- total weight and the minimal top-K with sum >= cdf_thresh * total ----
     int K = 0;
     bool bad = false;
+    double vlast = INFINITY; int jlast = -1;             // the last (weight, column) excluded; wave-uniform
     if (ok) {
         double tot = 0.0;
         bool wnan = false;
@@ -77,15 +79,13 @@ static __global__ __launch_bounds__(256) void k_kde_cdf(const KdeView* __restric
         if (__any(wnan)) ok = false;                     // nan cdf: nothing is selected (zeros)
         double excluded = 0.0;
         while (ok && K < n && (tot - excluded) > (1.0 - cdf_thresh) * tot) {
-            if (K == FZ_CDF_MAXK) { bad = true; break; }
             double best = -INFINITY; int bj = 0x7fffffff;
             for (int j0 = 0; j0 < n; j0 += 64) {
                 const int j = j0 + lane;
                 if (j < n) {
-                    bool ex = false;
-                    for (int q = 0; q < K; ++q) ex |= (excl[q] == j);
                     const double w = weight(j);
-                    if (!ex && w > best) { best = w; bj = j; }
+                    const bool ex = (w > vlast) || (w == vlast && j <= jlast);
+                    if (!ex && w > best) { best = w; bj = j; }     // (a lane's columns ascend: the first of equal weights stays)
                 }
             }
             const double wbest = wave_max(best);
@@ -93,21 +93,18 @@ static __global__ __launch_bounds__(256) void k_kde_cdf(const KdeView* __restric
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) cand = min(cand, __shfl_xor(cand, s, 64));
             if (cand == 0x7fffffff) break;               // nothing left (all -inf / empty)
-            if (lane == 0) excl[K] = cand;
+            vlast = wbest; jlast = cand;
             ++K;
             excluded += wbest;
         }
     }
-    if (bad) { if (lane == 0) atomicExch(errflag, 2); return; }
-
     // ---- stack every other kernel, unthresholded (pdf.py:599-620 / 519-524) ----
     for (int t = lane; t < acc_stride; t += 64) row[t] = 0.0;
     if (ok) {
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            bool sel = j < n;
-            if (sel) for (int q = 0; q < K; ++q) sel &= (excl[q] != j);
             const double w = (j < n) ? weight(j) : 0.0;
+            bool sel = (j < n) && !((w > vlast) || (w == vlast && j <= jlast));
             int64_t jm = 0;
             if (j < n) { jm = nbr ? nbr[i * (int64_t)L + j] : j; if (jm < 0 || jm >= M) { bad = true; jm = 0; sel = false; } }
             kde_scatter(kv, row, sel, w, jm, lane);

@@ -72,6 +72,11 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
     return __hiloint2double(__double2hiint(v) + ((n >> 8) << 20), __double2loint(v));
 }
 
+typedef double plane_d4 __attribute__((ext_vector_type(4)));
+
+// K steps (of four) of the convolution as a matrix product, see the epilogue of k_plane_rows
+__host__ __device__ inline int plane_conv_ksteps(int w2) { return (16 + w2 + 3) >> 2; }
+
 template <int NW, int E2>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_plane_rows(const double* __restrict__ plane, int64_t ld, const KdeView* __restrict__ kvp,
                                                          int acc_stride, int64_t N, int M, double wt_thresh, int normalize,
@@ -87,6 +92,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     int* s_tag = s_amb + NW;                                // [NT E2] padded label indices of models 2 k, 2 k + 1 in the halves of word k
     double* s_ambl = reinterpret_cast<double*>(s_tag + NT * E2);    // [CAPA] ln-weights within rounding of the threshold (decided once the evidence is known)
     int* s_ambp = reinterpret_cast<int*>(s_ambl + CAPA);            // [CAPA] their histogram indices
+#ifndef FZ_PLANE_VALU_CONV
+    double* s_T = reinterpret_cast<double*>(s_ambp + CAPA);        // [KS 64] the kernel taps as the B operands of the convolution's matrix product
+#endif
     // (each exchange array is written in one barrier interval and read in the next one only, so a wave that runs ahead into
     //  the next object can never overwrite what a slower one still reads)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,11 +112,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         const int p0 = (j < M) ? kv.pos[j] + w0 : 0, p1 = (j + 1 < M) ? kv.pos[j + 1] + w0 : 0;
         s_tag[k] = p0 | (p1 << 16);
     }
-    // dictionary kernel taps across the wave (as in kde_finalize)
     const double* kr = kv.kern + kv.koff0;
+#ifdef FZ_PLANE_VALU_CONV
+    // dictionary kernel taps across the wave (as in kde_finalize)
     const double ka = (lane <= w2) ? kr[lane] : 0.0;
     const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
     const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
+#else
+    // The convolution out[t] = sum_h row[t + h] kr[w2 - h] as a matrix product on the fp64 matrix pipe: with t = 16 a + b,
+    // out[16 a + b] = sum_j R[a][j] T[j][b],  R[a][j] = row[16 a + j] (overlapping windows of the histogram),
+    // T[j][b] = kr[w2 - (j - b)] for 0 <= j - b <= w2, else 0 -- a constant banded Toeplitz matrix, (16 + w2) x 16.
+    // One v_mfma_f64_16x16x4 takes 16 windows (256 outputs) through four values of j; a wave owns 256 outputs.  T is staged
+    // once per block in the operand layout of the instruction (lane: k = lane >> 4, column b = lane & 15).
+    const int KS = plane_conv_ksteps(w2);
+    for (int k = tid; k < KS * 64; k += NT) {
+        const int h = 4 * (k >> 6) + ((k & 63) >> 4) - (k & 15);
+        s_T[k] = (h >= 0 && h <= w2) ? kr[w2 - h] : 0.0;
+    }
+#endif
     const double thr_hi = uniform_d(wt_thresh * (1.0 + 1e-9)), thr_lo = uniform_d(wt_thresh * (1.0 - 1e-9));     // wave-uniform values live in scalar registers
     __syncthreads();
 
@@ -142,7 +163,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     };
     // the taps were loaded above and are first used inside the convolution: consumed here, so that the compiler's wait for
     // them sits before the object loop and not in the tap loop, where it would also wait for the next row in flight
+#ifdef FZ_PLANE_VALU_CONV
     asm volatile("" :: "v"(kal), "v"(kah), "v"(kbl), "v"(kbh));
+#endif
     int64_t i = blockIdx.x;
     if (i < N) load_row(i);
     int par = 0;
@@ -270,7 +293,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             int t0 = tid;
             asm volatile("" : "+v"(t0));
             for (int t = t0; t < G; t += NT) out[t] = NAN;
-        } else if (wave * 128 < G) {                                         // wave-uniform; G <= NW * 128 (launcher): one pass, two outputs per lane
+        }
+#ifndef FZ_PLANE_VALU_CONV
+        else if (wave * 256 < G) {                                           // wave-uniform: this wave's 256 outputs on the matrix pipe; the other waves go on to the next row
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                                     // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
+            const int base = wave * 256 + 16 * (ln & 15) + (ln >> 4);        // A operand: window a = lane & 15 of this wave, k = lane >> 4
+            const double* tp = s_T + ln;
+            plane_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < KS; ++ks) {
+                // (indices past the padded row belong to taps that are zero or to outputs beyond the grid: any finite entry serves)
+                const double a = row[min(base + 4 * ks, GP - 1)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tp[ks * 64], acc, 0, 0, 0);
+            }
+            // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
+            // (the taps that land on the grid) = the sum of the stacked weights -- known since barrier (2), no second reduction
+            const double scale = normalize ? 1.0 / T : 1.0 / S;
+            // D: column b = lane & 15, window a = (lane >> 4) + 4 r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = wave * 256 + 16 * ((ln >> 4) + 4 * r) + (ln & 15);
+                if (t < G) out[t] = acc[r] * scale;
+            }
+        }
+#else
+        else if (wave * 128 < G) {                                           // wave-uniform; G <= NW * 128 (launcher): one pass, two outputs per lane
             int lo = lane;
             asm volatile("" : "+v"(lo));                                     // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
             const int t = wave * 128 + lo;
@@ -278,6 +325,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             const double* r0 = row + (one ? t : 0);
             const double* r1 = row + (two ? t + 64 : 0);
             double v0 = 0.0, v1 = 0.0;
+#ifdef FZ_DIAG_NOCONV
+            v0 = r0[w0]; v1 = r1[w0];
+#else
             const int hs = w2 < 64 ? 0 : w2 - 63;
             for (int h = 0; h < hs; ++h) {
                 const int q = w2 - h - 64;
@@ -302,12 +352,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 const double tap = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
                 v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
             }
+#endif
             // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
             // (the taps that land on the grid) = the sum of the stacked weights -- known since barrier (2), no second reduction
             const double scale = normalize ? 1.0 / T : 1.0 / S;
             if (one) out[t] = v0 * scale;
             if (two) out[t + 64] = v1 * scale;
         }
+#endif
     }
 }
 

@@ -302,6 +302,30 @@ def test_two_pass_fallback_matches_single_pass():
     close(p2[:40], rp, rtol=1e-8, atol=1e-14)
 
 
+def test_cdf_rule_with_hundreds_of_exclusions():
+    """pdf.py:593-597 has no limit on how many of the largest weights the CDF rule drops: a nearly flat weight row over
+    4 000 kernels at cdf_thresh 0.1 / 0.5 drops ~400 / ~2 000 of them (until round 4 the kernel refused more than 64),
+    with runs of EQUAL weights straddling the boundary (distinct values only, so that the reference's unstable argsort
+    cannot reorder the tie the boundary falls into)."""
+    from frankenz_amd import pdf as hp
+    d, od = dicts()
+    rs = np.random.RandomState(77)
+    n = 4000
+    y, ys = rs.uniform(0.5, 6.5, n), rs.uniform(0.02, 0.3, n)
+    wt = 1. + 1e-3 * rs.permutation(n)                                   # distinct, nearly flat
+    for cdf in (0.1, 0.5, 0.9):
+        want = fo.gauss_kde_dict(od, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=cdf)
+        close(hp.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=cdf), want, atol=1e-13)
+    grid = np.arange(0, 7 + 1e-5, .01)
+    close(hp.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None, cdf_thresh=0.3),
+          fo.gauss_kde(y, ys, grid, y_wt=wt, wt_thresh=None, cdf_thresh=0.3), atol=1e-13)
+    # whole tie groups beyond the boundary: the PDF is independent of which members of a group are taken only when the
+    # members are the same kernel, so the tied weights share one (y, y_std)
+    wt2 = np.repeat(np.arange(1., 41.), 100); y2 = np.repeat(rs.uniform(1, 6, 40), 100); ys2 = np.repeat(rs.uniform(.05, .2, 40), 100)
+    close(hp.gauss_kde_dict(d, y=y2, y_std=ys2, y_wt=wt2, wt_thresh=None, cdf_thresh=0.37),
+          fo.gauss_kde_dict(od, y=y2, y_std=ys2, y_wt=wt2, wt_thresh=None, cdf_thresh=0.37), rtol=1e-9, atol=1e-13)
+
+
 @pytest.mark.parametrize('kw', [{}, {'free_scale': True, 'ignore_model_err': True},
                                 {'free_scale': True, 'ignore_model_err': False}])
 def test_cdf_threshold_rule_through_the_classes(kw):
