@@ -183,3 +183,47 @@ def test_register_allocation_of_the_hand_scheduled_kernels():
             seen['k_knn_mfma'] += 1
             assert get(r'ScratchSize \[bytes/lane\]') == 0 and get(r'Occupancy \[waves/SIMD\]') >= 4, name
     assert seen['k_plane_rows'] >= 3 and seen['k_knn_mfma'] >= 1, seen
+
+
+def test_nothing_touches_a_row_register_of_k_plane_rows_while_its_load_is_in_flight():
+    """The row loads of k_plane_rows are inline asm the compiler does not count (`global_load_dwordx4 ... nt`), waited for by a
+    hand-placed `s_waitcnt vmcnt(0)`.  Zero scratch (the test above) is necessary, not sufficient: a register COPY of an entry
+    between the two reads the register before the data lands just the same -- round 4 saw both when the loads were moved into
+    the weighing loop (`scratch_store_dwordx4 v[2:5]` on the line after `global_load_dwordx4 v[2:5]`; a second register set with
+    a copy at the loop's end).  The build keeps the kernel's machine code; here every instruction in layout order between a row
+    load and the next full wait is checked for operands inside the registers being loaded."""
+    import __graft_entry__ as ge
+    ge.build()
+    if not os.path.exists(ge.PLANE_ISA):
+        ge.build(force=True)
+    vreg = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+    nfun = nload = 0
+    pending, fun = set(), None
+    for line in open(ge.PLANE_ISA):
+        code = line.split(';')[0].strip()
+        if line.startswith('_ZN2fz12k_plane_rows'):
+            fun, pending = line.split(':')[0], set()
+            nfun += 1
+            continue
+        if not code or code.startswith('.') or code.endswith(':'):
+            continue
+        regs = set()
+        for m in vreg.finditer(code):
+            if m.group(1) is not None:
+                regs.add(int(m.group(1)))
+            else:
+                regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        if code.startswith('global_load_dwordx4') and code.endswith(' nt'):
+            dst = vreg.search(code)
+            dreg = set(range(int(dst.group(2)), int(dst.group(3)) + 1))
+            addr = regs - dreg if code.count('v[') == 1 else set()
+            assert not (addr & pending), (fun, code)
+            assert not (dreg & pending), (fun, code, 'a second request into registers still in flight')
+            pending |= dreg
+            nload += 1
+            continue
+        if code.startswith('s_waitcnt') and 'vmcnt(0)' in code:
+            pending = set()
+            continue
+        assert not (regs & pending), (fun, code, sorted(regs & pending))
+    assert nfun >= 3 and nload >= 3 * 2 * 5, (nfun, nload)
