@@ -79,9 +79,9 @@ int fz_launch_plane_rows_g(fz_ctx* c, const double* plane, const fz::KdeView& kv
                            double* lmap, double* levid, double* pdfs) {
     auto kern = fz::k_plane_rows<NW, E2>;
     constexpr size_t NT = (size_t)NW * 64;
-    // exp table | two histogram rows | 1 / mass | exchange words | flags | label indices of the lanes' columns | parked ties
-    // ... | the kernel taps as matrix operands
-    const size_t lds = ((size_t)FZ_HEXP_K + 3 * (size_t)kv.acc_stride + 3 * NW + 2) * 8 + 2 * NW * 4 + NT * E2 * 4 + NT * 12 +
+    // exp table | three histogram rows + 1 / mass | exchange words (two parities) | flags, tie counts | label indices of the lanes'
+    // columns | parked ties | the kernel taps as matrix operands
+    const size_t lds = ((size_t)FZ_HEXP_K + 4 * (size_t)kv.acc_stride + 6 * NW + 2) * 8 + (2 * NW + 2) * 4 + NT * E2 * 4 + NT * 12 +
                        (size_t)fz::plane_conv_ksteps(2 * kv.w0) * 64 * 8;
     if (lds > 160 * 1024) return 1;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

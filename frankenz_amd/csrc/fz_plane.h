@@ -84,27 +84,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     constexpr int NT = NW * 64, CAPA = NT;
     extern __shared__ double smem[];
     double* s_exp = smem;                               // [FZ_HEXP_K] 2^(k/256)
-    double* rowA = s_exp + FZ_HEXP_K;                   // [acc_stride] x 2: the histograms of this object and of the next one (padded by w0 on either side)
-    double* s_inv = rowA + 2 * acc_stride;              // [acc_stride] 1 / kernel mass per padded index
-    double* s_red = s_inv + acc_stride;                 // [3 NW + 2] per-wave maxima, sums, stacked sums; the late (ambiguous) stacked sum
-    int* s_flag = reinterpret_cast<int*>(s_red + 3 * NW + 2);   // [NW] bit 0: a nan in the wave's part, bit 1: the row's first entry is nan
-    int* s_amb = s_flag + NW;                               // [NW] word 0: entries within rounding of the threshold (count)
-    int* s_tag = s_amb + NW;                                // [NT E2] padded label indices of models 2 k, 2 k + 1 in the halves of word k
+    double* hist = s_exp + FZ_HEXP_K;                   // [acc_stride] x 3: the histograms of the row being weighed, of the previous one (its epilogue) and the one being cleared
+    double* s_inv = hist + 3 * acc_stride;              // [acc_stride] 1 / kernel mass per padded index
+    double* s_max = s_inv + acc_stride;                 // [2][NW] per-wave maxima (by the parity of the row)
+    double* s_sum = s_max + 2 * NW;                     // [2][2 NW] per-wave sums and stacked sums
+    double* s_late = s_sum + 4 * NW;                    // [2] the late (ambiguous) stacked sum
+    int* s_flag = reinterpret_cast<int*>(s_late + 2);   // [2][NW] bit 0: a nan in the wave's part, bit 1: the row's first entry is nan
+    int* s_amb = s_flag + 2 * NW;                       // [2] entries within rounding of the threshold (count)
+    int* s_tag = s_amb + 2;                             // [NT E2] padded label indices of models 2 k, 2 k + 1 in the halves of word k
     double* s_ambl = reinterpret_cast<double*>(s_tag + NT * E2);    // [CAPA] ln-weights within rounding of the threshold (decided once the evidence is known)
     int* s_ambp = reinterpret_cast<int*>(s_ambl + CAPA);            // [CAPA] their histogram indices
-#ifndef FZ_PLANE_VALU_CONV
     double* s_T = reinterpret_cast<double*>(s_ambp + CAPA);        // [KS 64] the kernel taps as the B operands of the convolution's matrix product
-#endif
-    // (each exchange array is written in one barrier interval and read in the next one only, so a wave that runs ahead into
-    //  the next object can never overwrite what a slower one still reads)
+    // (each exchange array is written in one barrier interval and read in the next one only -- two copies by the parity of the
+    //  row -- so a wave that runs ahead into the next row can never overwrite what a slower one still reads)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const KdeView kv = *kvp;
     const int G = (int)kv.G, w0 = kv.w0, w2 = 2 * w0, GP = G + w2;
     const FastTabs tb = global_tabs();
     for (int k = tid; k < FZ_HEXP_K; k += NT) s_exp[k] = FZ_EXP_TAB[k * (FZ_EXP_K / FZ_HEXP_K)];
-    for (int k = tid; k < acc_stride; k += NT) { rowA[k] = 0.0; rowA[acc_stride + k] = 0.0; s_inv[k] = (k < GP) ? 1.0 / kv.normtab[k] : 1.0; }
-    if (tid == 0) { s_red[3 * NW] = 0.0; s_amb[0] = 0; }
+    for (int k = tid; k < acc_stride; k += NT) {
+        hist[k] = 0.0; hist[acc_stride + k] = 0.0; hist[2 * acc_stride + k] = 0.0;
+        s_inv[k] = (k < GP) ? 1.0 / kv.normtab[k] : 1.0;
+    }
+    if (tid < 2) { s_late[tid] = 0.0; s_amb[tid] = 0; }
     // a lane holds the same model columns for every object -- entry e: models 2 (e NT + tid) and +1 -- so their label indices
     // are staged once (LDS rather than registers: the row itself takes 4 E2 of them)
     for (int k = tid; k < NT * E2; k += NT) {
@@ -112,24 +115,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         const int p0 = (j < M) ? kv.pos[j] + w0 : 0, p1 = (j + 1 < M) ? kv.pos[j + 1] + w0 : 0;
         s_tag[k] = p0 | (p1 << 16);
     }
-    const double* kr = kv.kern + kv.koff0;
-#ifdef FZ_PLANE_VALU_CONV
-    // dictionary kernel taps across the wave (as in kde_finalize)
-    const double ka = (lane <= w2) ? kr[lane] : 0.0;
-    const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
-    const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
-#else
     // The convolution out[t] = sum_h row[t + h] kr[w2 - h] as a matrix product on the fp64 matrix pipe: with t = 16 a + b,
     // out[16 a + b] = sum_j R[a][j] T[j][b],  R[a][j] = row[16 a + j] (overlapping windows of the histogram),
     // T[j][b] = kr[w2 - (j - b)] for 0 <= j - b <= w2, else 0 -- a constant banded Toeplitz matrix, (16 + w2) x 16.
     // One v_mfma_f64_16x16x4 takes 16 windows (256 outputs) through four values of j; a wave owns 256 outputs.  T is staged
     // once per block in the operand layout of the instruction (lane: k = lane >> 4, column b = lane & 15).
+    const double* kr = kv.kern + kv.koff0;
     const int KS = plane_conv_ksteps(w2);
     for (int k = tid; k < KS * 64; k += NT) {
         const int h = 4 * (k >> 6) + ((k & 63) >> 4) - (k & 15);
         s_T[k] = (h >= 0 && h <= w2) ? kr[w2 - h] : 0.0;
     }
-#endif
     const double thr_hi = uniform_d(wt_thresh * (1.0 + 1e-9)), thr_lo = uniform_d(wt_thresh * (1.0 - 1e-9));     // wave-uniform values live in scalar registers
     __syncthreads();
 
@@ -137,7 +133,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     // Row loads by hand: scalar base (the row) + ONE lane offset per entry formed on the spot, so the E2 requests need no
     // address registers beside the E2 x 4 they fill (the compiler's form: a 64-bit address pair and a branch per entry, and
     // parts of the row spilled to scratch).  Lanes past the end of a short row re-read its last entry and are set to -inf when
-    // the data are used.  The compiler does not count these loads: row_wait() is the s_waitcnt, tied to every register of the row.
+    // the data are used.  The compiler does not count these loads: row_wait() is the s_waitcnt, tied to every register of the row
+    // (tests/test_abi.py checks the compiled code: nothing touches a row register between its request and the wait).
     const int last2 = M / 2 - 1;
     auto load_row = [&](int64_t i) {
         const char* rb = reinterpret_cast<const char*>(plane + i * ld);
@@ -161,205 +158,185 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 if (2 * (e * NT + tid) >= M) l[e] = fz_d2{-INFINITY, -INFINITY};
             }
     };
-    // the taps were loaded above and are first used inside the convolution: consumed here, so that the compiler's wait for
-    // them sits before the object loop and not in the tap loop, where it would also wait for the next row in flight
-#ifdef FZ_PLANE_VALU_CONV
-    asm volatile("" :: "v"(kal), "v"(kah), "v"(kbl), "v"(kbh));
-#endif
+
+    // ONE block barrier per row.  Iteration i: wait for row i, post its per-wave maxima, BARRIER -- behind it the maxima of row i
+    // are complete, and so are the sums and the histogram of row i - 1 (posted / added before the barrier) -- then: clear the
+    // histogram row i + 1 will use, settle the parked ties of row i - 1 (rare), weigh row i into its histogram, request row i + 1,
+    // post the sums of row i, and only then the EPILOGUE OF ROW i - 1 (ln-evidence by wave 0, convolution by the waves that own
+    // outputs, store) while the other waves already wait for row i + 1: the epilogue runs under the memory latency of the next row
+    // instead of in front of it.  Three histograms rotate (weighed / convolved / cleared); every exchange word has a copy per row parity.
     int64_t i = blockIdx.x;
     if (i < N) load_row(i);
-    int par = 0;
-    for (; i < N; i += gridDim.x, par ^= 1) {
-        double* row = rowA + par * acc_stride;                               // this object's histogram (zero: cleared one object ago)
-        double* rowz = rowA + (par ^ 1) * acc_stride;                        // the previous object's: cleared below, once every wave is past its convolution
-        const int64_t inext = i + gridDim.x;
-        row_wait();
-        // ---- exact maximum (nan never becomes the best: v_max_f64 returns the other operand) ----
-        double m = -INFINITY;
-        bool an = false;
+    bool havep = false;                                                      // a previous row waits for its epilogue (block-uniform)
+    int64_t ip = 0;
+    double mxp = 0.0;
+    int flp = 0;
+    int par = 0, hb = 0;
+    while (true) {
+        const bool have = i < N;                                             // block-uniform
+        if (!have && !havep) break;
+        if (have) {
+            row_wait();
+            // ---- per-wave maximum (nan never becomes the best: v_max_f64 returns the other operand) ----
+            double m = -INFINITY;
+            bool an = false;
 #pragma unroll
-        for (int e = 0; e < E2; ++e) {
-            m = vmax_raw(m, l[e].x); m = vmax_raw(m, l[e].y);
-            an |= (l[e].x != l[e].x) | (l[e].y != l[e].y);
+            for (int e = 0; e < E2; ++e) {
+                m = vmax_raw(m, l[e].x); m = vmax_raw(m, l[e].y);
+                an |= (l[e].x != l[e].x) | (l[e].y != l[e].y);
+            }
+            const bool fnl = (tid == 0) && (l[0].x != l[0].x);
+            m = wave_max_dpp(m);
+            const int wf = (__any(an) ? 1 : 0) | (__any(fnl) ? 2 : 0);
+            if (lane == 0) { s_max[par * NW + wave] = m; s_flag[par * NW + wave] = wf; }
         }
-        const bool fnl = (tid == 0) && (l[0].x != l[0].x);
-        m = wave_max_dpp(m);
-        const int wf = (__any(an) ? 1 : 0) | (__any(fnl) ? 2 : 0);
-        if (lane == 0) { s_red[wave] = m; s_flag[wave] = wf; }
-        __syncthreads();                                                     // (1)
+        __syncthreads();                                                     // the row's one barrier
+        double* row = hist + hb * acc_stride;                                // row i (zero: cleared one row ago)
+        double* rowp = hist + (hb == 0 ? 2 : hb - 1) * acc_stride;           // row i - 1: complete, convolved below
         {
+            double* rowz = hist + (hb == 2 ? 0 : hb + 1) * acc_stride;       // row i - 2: its epilogue ended before the barrier; cleared for row i + 1
             int tz = tid;
             asm volatile("" : "+v"(tz));
             for (int k = tz; k < GP; k += NT) rowz[k] = 0.0;
         }
-        double mx = s_red[0];
-        int fl = s_flag[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) { mx = vmax_raw(mx, s_red[w]); fl |= s_flag[w]; }
-        mx = uniform_d(mx);
-        fl = __builtin_amdgcn_readfirstlane(fl);
-        const bool anynan = fl & 1, firstnan = fl & 2;
-        const bool tame = (mx - mx == 0.0);                                  // a finite best
-        // ---- weights against the maximum, evidence sum, histogram ----
-        double s = 0.0, ssel = 0.0;
-        if (tame) {
-            int tt = tid;
-            asm volatile("" : "+v"(tt));
-            const int* tg = s_tag + tt;
-#pragma unroll
-            for (int e = 0; e < E2; ++e) {
-                const int pt = tg[e * NT];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const double lv = q ? l[e].y : l[e].x;
-                    const double w = exp_nonpos_tab(lv - mx, s_exp);        // -inf, nan and pad columns: 1e-304
-                    s += w;
-                    if (w >= thr_lo) {                                       // stacked, or within rounding of the threshold
-                        const int p = q ? (pt >> 16) : (pt & 0xffff);
-                        if (w > thr_hi) {
-                            ssel += w;
-                            unsafeAtomicAdd(&row[p], w * s_inv[p]);         // weight / kernel mass of the index (pdf.py:613-617)
-                        } else {                                             // (rare) parked until the evidence is known
-                            const int k = atomicAdd(&s_amb[0], 1);
-                            if (k < CAPA) { s_ambl[k] = lv; s_ambp[k] = p; }   // (more than CAPA of them: the row is read again below)
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);                           // two entries at a time (all E2 at once spill the row)
-            }
-        }
-        // ---- the row is used up: the next one is requested now, and everything below touches LDS and registers only ----
-        if (inext < N) load_row(inext);
-        s = wave_sum_dpp(s);
-        ssel = wave_sum_dpp(ssel);
-        if (lane == 0) { s_red[NW + wave] = s; s_red[2 * NW + wave] = ssel; }
-        __syncthreads();                                                     // (2)
+        // ---- row i - 1: its sums; its parked ties (block-uniform, rare): the reference's own expression decides ----
         double S = 0.0, T = 0.0;
+        bool okp = false;
+        if (havep) {
+            const double* ss = s_sum + (par ^ 1) * 2 * NW;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { S += s_red[NW + w]; T += s_red[2 * NW + w]; }
-        S = uniform_d(S); T = uniform_d(T);
-        const int namb = __builtin_amdgcn_readfirstlane(s_amb[0]);
-        const bool ok = !anynan && tame;                                     // a finite evidence: S >= 1 (the best entry itself)
-        if (namb) {                                                          // block-uniform, rare: the reference's own expression decides
-            if (ok) {
-                const double le = mx + log_by_exp(S, s_exp);
-                const double thr = wt_thresh * exp_neg(mx - le, tb);        // wt_thresh * max(wt)
-                if (namb <= CAPA) {
-                    for (int k = tid; k < namb; k += NT) {
-                        const double lv = s_ambl[k];
-                        const int p = s_ambp[k];
-                        if (exp_neg(lv - le, tb) > thr) {                   // strict
-                            const double w = exp_nonpos_tab(lv - mx, s_exp);
-                            unsafeAtomicAdd(&row[p], w * s_inv[p]);
-                            unsafeAtomicAdd(&s_red[3 * NW], w);
+            for (int w = 0; w < NW; ++w) { S += ss[w]; T += ss[NW + w]; }
+            S = uniform_d(S); T = uniform_d(T);
+            const int namb = __builtin_amdgcn_readfirstlane(s_amb[par ^ 1]);
+            okp = !(flp & 1) && (mxp - mxp == 0.0);                          // a finite evidence: S >= 1 (the best entry itself)
+            if (namb) {
+                if (okp) {
+                    const double le = mxp + log_by_exp(S, s_exp);
+                    const double thr = wt_thresh * exp_neg(mxp - le, tb);   // wt_thresh * max(wt)
+                    if (namb <= CAPA) {
+                        for (int k = tid; k < namb; k += NT) {
+                            const double lv = s_ambl[k];
+                            const int p = s_ambp[k];
+                            if (exp_neg(lv - le, tb) > thr) {               // strict
+                                const double w = exp_nonpos_tab(lv - mxp, s_exp);
+                                unsafeAtomicAdd(&rowp[p], w * s_inv[p]);
+                                unsafeAtomicAdd(&s_late[par ^ 1], w);
+                            }
                         }
-                    }
-                } else {
-                    // more ties than the block parks (a degenerate row): its entries are read once more and the band decided in place
-                    const double* r = plane + i * ld;
-                    for (int k = tid; k < M / 2; k += NT) {
-                        const int pt = s_tag[k];
+                    } else {
+                        // more ties than the block parks (a degenerate row): its entries are read once more and the band decided in place
+                        const double* r = plane + ip * ld;
+                        for (int k = tid; k < M / 2; k += NT) {
+                            const int pt = s_tag[k];
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const double lv = r[2 * k + q];
-                            const double w = exp_nonpos_tab(lv - mx, s_exp);
-                            if (w >= thr_lo && !(w > thr_hi) && exp_neg(lv - le, tb) > thr) {
-                                const int p = q ? (pt >> 16) : (pt & 0xffff);
-                                unsafeAtomicAdd(&row[p], w * s_inv[p]);
-                                unsafeAtomicAdd(&s_red[3 * NW], w);
+                            for (int q = 0; q < 2; ++q) {
+                                const double lv = r[2 * k + q];
+                                const double w = exp_nonpos_tab(lv - mxp, s_exp);
+                                if (w >= thr_lo && !(w > thr_hi) && exp_neg(lv - le, tb) > thr) {
+                                    const int p = q ? (pt >> 16) : (pt & 0xffff);
+                                    unsafeAtomicAdd(&rowp[p], w * s_inv[p]);
+                                    unsafeAtomicAdd(&s_late[par ^ 1], w);
+                                }
                             }
                         }
                     }
                 }
-            }
-            __syncthreads();
-            T += uniform_d(s_red[3 * NW]);
-            __syncthreads();
-            if (tid == 0) { s_red[3 * NW] = 0.0; s_amb[0] = 0; }
-        }
-        if (wave == 0) {                                                     // ln-evidence: one wave, no tables (a table load would wait for the row in flight)
-            double le;
-            if (anynan) le = (double)NAN;
-            else if (!tame) le = mx;                                         // +inf, or -inf for a row of -inf
-            else le = mx + log_by_exp(S, s_exp);
-            if (lane == 0) {
-                if (lmap) lmap[i] = firstnan ? (double)NAN : mx;             // builtin max: NaN only if first
-                if (levid) levid[i] = le;
+                __syncthreads();
+                T += uniform_d(s_late[par ^ 1]);
+                __syncthreads();                                             // (the parked entries are free for row i from here on)
+                if (tid == 0) { s_late[par ^ 1] = 0.0; s_amb[par ^ 1] = 0; }   // this parity's next use lies behind the next barrier
             }
         }
-        // ---- PDF: convolve, normalise, write ----
-        double* out = pdfs + i * G;
-        if (!ok) {
-            int t0 = tid;
-            asm volatile("" : "+v"(t0));
-            for (int t = t0; t < G; t += NT) out[t] = NAN;
-        }
-#ifndef FZ_PLANE_VALU_CONV
-        else if (wave * 256 < G) {                                           // wave-uniform: this wave's 256 outputs on the matrix pipe; the other waves go on to the next row
-            int ln = lane;
-            asm volatile("" : "+v"(ln));                                     // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
-            const int base = wave * 256 + 16 * (ln & 15) + (ln >> 4);        // A operand: window a = lane & 15 of this wave, k = lane >> 4
-            const double* tp = s_T + ln;
-            plane_d4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int ks = 0; ks < KS; ++ks) {
-                // (indices past the padded row belong to taps that are zero or to outputs beyond the grid: any finite entry serves)
-                const double a = row[min(base + 4 * ks, GP - 1)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tp[ks * 64], acc, 0, 0, 0);
-            }
-            // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
-            // (the taps that land on the grid) = the sum of the stacked weights -- known since barrier (2), no second reduction
-            const double scale = normalize ? 1.0 / T : 1.0 / S;
-            // D: column b = lane & 15, window a = (lane >> 4) + 4 r
+        // ---- row i: exact maximum, weights against it, evidence sum, histogram ----
+        double mx = 0.0;
+        int fl = 0;
+        if (have) {
+            mx = s_max[par * NW];
+            fl = s_flag[par * NW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = wave * 256 + 16 * ((ln >> 4) + 4 * r) + (ln & 15);
-                if (t < G) out[t] = acc[r] * scale;
-            }
-        }
-#else
-        else if (wave * 128 < G) {                                           // wave-uniform; G <= NW * 128 (launcher): one pass, two outputs per lane
-            int lo = lane;
-            asm volatile("" : "+v"(lo));                                     // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
-            const int t = wave * 128 + lo;
-            const bool one = t < G, two = t + 64 < G;
-            const double* r0 = row + (one ? t : 0);
-            const double* r1 = row + (two ? t + 64 : 0);
-            double v0 = 0.0, v1 = 0.0;
-#ifdef FZ_DIAG_NOCONV
-            v0 = r0[w0]; v1 = r1[w0];
-#else
-            const int hs = w2 < 64 ? 0 : w2 - 63;
-            for (int h = 0; h < hs; ++h) {
-                const int q = w2 - h - 64;
-                const double tap = __hiloint2double(__builtin_amdgcn_readlane(kbh, q), __builtin_amdgcn_readlane(kbl, q));
-                v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
-            }
-            int h = hs;
-            for (; h + 3 <= w2; h += 4) {                                    // four taps' LDS reads in flight; the sums in the same order
-                double a[4], b[4], tp[4];
+            for (int w = 1; w < NW; ++w) { mx = vmax_raw(mx, s_max[par * NW + w]); fl |= s_flag[par * NW + w]; }
+            mx = uniform_d(mx);
+            fl = __builtin_amdgcn_readfirstlane(fl);
+            const bool tame = (mx - mx == 0.0);                              // a finite best
+            double s = 0.0, ssel = 0.0;
+            if (tame) {
+                int tt = tid;
+                asm volatile("" : "+v"(tt));
+                const int* tg = s_tag + tt;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { a[u] = r0[h + u]; b[u] = r1[h + u]; }
+                for (int e = 0; e < E2; ++e) {
+                    const int pt = tg[e * NT];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = w2 - h - u;
-                    tp[u] = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
+                    for (int q = 0; q < 2; ++q) {
+                        const double lv = q ? l[e].y : l[e].x;
+                        const double w = exp_nonpos_tab(lv - mx, s_exp);    // -inf, nan and pad columns: 1e-304
+                        s += w;
+                        if (w >= thr_lo) {                                   // stacked, or within rounding of the threshold
+                            const int p = q ? (pt >> 16) : (pt & 0xffff);
+                            if (w > thr_hi) {
+                                ssel += w;
+                                unsafeAtomicAdd(&row[p], w * s_inv[p]);     // weight / kernel mass of the index (pdf.py:613-617)
+                            } else {                                         // (rare) parked until the evidence is known
+                                const int k = atomicAdd(&s_amb[par], 1);
+                                if (k < CAPA) { s_ambl[k] = lv; s_ambp[k] = p; }   // (more than CAPA of them: the row is read again)
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                       // two entries at a time (all E2 at once spill the row)
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { v0 = fma(a[u], tp[u], v0); v1 = fma(b[u], tp[u], v1); }
             }
-            for (; h <= w2; ++h) {
-                const int q = w2 - h;
-                const double tap = __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q));
-                v0 = fma(r0[h], tap, v0); v1 = fma(r1[h], tap, v1);
-            }
-#endif
-            // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
-            // (the taps that land on the grid) = the sum of the stacked weights -- known since barrier (2), no second reduction
-            const double scale = normalize ? 1.0 / T : 1.0 / S;
-            if (one) out[t] = v0 * scale;
-            if (two) out[t + 64] = v1 * scale;
+            // ---- the row is used up: the next one is requested now, and everything below touches LDS and registers only ----
+            const int64_t inext = i + gridDim.x;
+            if (inext < N) load_row(inext);
+            s = wave_sum_dpp(s);
+            ssel = wave_sum_dpp(ssel);
+            if (lane == 0) { s_sum[par * 2 * NW + wave] = s; s_sum[par * 2 * NW + NW + wave] = ssel; }
         }
-#endif
+        // ---- epilogue of row i - 1, under the latency of row i + 1 ----
+        if (havep) {
+            const bool anynan = flp & 1, firstnan = flp & 2;
+            if (wave == 0) {                                                 // ln-evidence: one wave, no tables (a table load would wait for the row in flight)
+                double le;
+                if (anynan) le = (double)NAN;
+                else if (!(mxp - mxp == 0.0)) le = mxp;                      // +inf, or -inf for a row of -inf
+                else le = mxp + log_by_exp(S, s_exp);
+                if (lane == 0) {
+                    if (lmap) lmap[ip] = firstnan ? (double)NAN : mxp;       // builtin max: NaN only if first
+                    if (levid) levid[ip] = le;
+                }
+            }
+            // ---- PDF: convolve, normalise, write ----
+            double* out = pdfs + ip * G;
+            if (!okp) {
+                int t0 = tid;
+                asm volatile("" : "+v"(t0));
+                for (int t = t0; t < G; t += NT) out[t] = NAN;
+            } else if (wave * 256 < G) {                                     // wave-uniform: this wave's 256 outputs on the matrix pipe
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                                 // (addresses formed per object: hoisted, they spill -- and a scratch reload here would wait for the row in flight)
+                const int base = wave * 256 + 16 * (ln & 15) + (ln >> 4);    // A operand: window a = lane & 15 of this wave, k = lane >> 4
+                const double* tp = s_T + ln;
+                plane_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int ks = 0; ks < KS; ++ks) {
+                    // (indices past the padded row belong to taps that are zero or to outputs beyond the grid: any finite entry serves)
+                    const double a = rowp[min(base + 4 * ks, GP - 1)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tp[ks * 64], acc, 0, 0, 0);
+                }
+                // pdf /= pdf.sum(): the sum over the grid of the convolved histogram is the sum over the indices of (weight / mass) x
+                // (the taps that land on the grid) = the sum of the stacked weights -- known since the sums were exchanged, no second reduction
+                const double scale = normalize ? 1.0 / T : 1.0 / S;
+                // D: column b = lane & 15, window a = (lane >> 4) + 4 r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = wave * 256 + 16 * ((ln >> 4) + 4 * r) + (ln & 15);
+                    if (t < G) out[t] = acc[r] * scale;
+                }
+            }
+        }
+        havep = have; ip = i; mxp = mx; flp = fl;
+        if (have) i += gridDim.x;
+        par ^= 1;
+        hb = (hb == 2) ? 0 : hb + 1;
     }
 }
 
