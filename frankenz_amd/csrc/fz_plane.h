@@ -69,7 +69,11 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     const double v = t * p;                                      // in [1,2)
+#ifdef FZ_PLANE_EXP_BITS
     return __hiloint2double(__double2hiint(v) + ((n >> 8) << 20), __double2loint(v));
+#else
+    return __builtin_amdgcn_ldexp(v, n >> 8);                    // (n >> 8 >= -1011: a normal number, the same bits as the exponent-field add)
+#endif
 }
 
 typedef double plane_d4 __attribute__((ext_vector_type(4)));
@@ -140,10 +144,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         const char* rb = reinterpret_cast<const char*>(plane + i * ld);
         int t = tid;
         asm volatile("" : "+v"(t));                                          // offsets formed here, per row (hoisted, the E2 of them spill)
+        const unsigned off0 = (unsigned)t * 16u;
 #pragma unroll
         for (int e = 0; e < E2; ++e) {
-            const unsigned off = (unsigned)min(e * NT + t, last2) * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(l[e]) : "v"(off), "s"(rb) : "memory");
+            if (2 * (e + 1) * NT <= M) {                                     // wave-uniform: the entry lies inside the row for every lane -- the lane's own
+                // offset and the entry's start in the SCALAR base (two scalar adds instead of three vector instructions per request)
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(l[e]) : "v"(off0), "s"(rb + (size_t)e * NT * 16) : "memory");
+            } else {
+                const unsigned off = (unsigned)min(e * NT + t, last2) * 16u;
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(l[e]) : "v"(off), "s"(rb) : "memory");
+            }
         }
     };
     auto row_wait = [&]() {
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
             for (int e = 0; e < E2; ++e) {
                 m = vmax_raw(m, l[e].x); m = vmax_raw(m, l[e].y);
-                an |= (l[e].x != l[e].x) | (l[e].y != l[e].y);
+                an |= __builtin_isunordered(l[e].x, l[e].y);                  // one compare: either of the pair is a nan
             }
             const bool fnl = (tid == 0) && (l[0].x != l[0].x);
             m = wave_max_dpp(m);
@@ -203,11 +213,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         double S = 0.0, T = 0.0;
         bool okp = false;
         if (havep) {
-            const double* ss = s_sum + (par ^ 1) * 2 * NW;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { S += ss[w]; T += ss[NW + w]; }
-            S = uniform_d(S); T = uniform_d(T);
             const int namb = __builtin_amdgcn_readfirstlane(s_amb[par ^ 1]);
+            if (namb || wave * 256 < G) {                                    // the sums: only the waves that write outputs (wave 0 among them) -- and everyone for the ties
+                const double* ss = s_sum + (par ^ 1) * 2 * NW;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { S += ss[w]; T += ss[NW + w]; }
+                S = uniform_d(S); T = uniform_d(T);
+            }
             okp = !(flp & 1) && (mxp - mxp == 0.0);                          // a finite evidence: S >= 1 (the best entry itself)
             if (namb) {
                 if (okp) {

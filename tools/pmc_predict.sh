@@ -1,10 +1,11 @@
 #!/bin/bash
-# PMC passes for predict() from a stored plane (k_plane_fused): per-launch sums.  -> gpurun_out/pmc_predict.txt
+# PMC passes for predict() from a stored plane (k_plane_rows / k_plane_fused): per-launch sums.  -> gpurun_out/pmc_predict.txt
 export TMPDIR=/tmp
 ARGS="--workload predict --nobj ${NOBJ:-100000} --nmodel ${NMODEL:-10000} --steps 2 --warmup 1 --no-cpu"
 SETS=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
   "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH"
+  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU"
   "FETCH_SIZE"
   "WRITE_SIZE"
 )
