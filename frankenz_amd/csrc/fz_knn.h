@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void k_knn_query32(const float* __restrict__ f
 // subset likelihood + PDF, one object per wave
 // ---------------------------------------------------------------------------
 // capacities per launch: wcap = K*k rounded up to a power of two (>= 64), hash table of 2 wcap slots (open addressing)
-#define FZ_KNN_WMAX 4096          // largest K*k handled (k <= 64 per set, any K up to 64: the reference takes any; knn.py:190-193)
+#define FZ_KNN_WMAX 4096          // largest K*k handled (the reference takes any; knn.py:190-193)
+#define FZ_KNN_KMAX 256           // largest k: the matrix-pipe Euclidean search keeps longer lists in 64-entry segments; the other norms / wide feature sets stop at 64
 __host__ __device__ inline int fz_knn_wcap(int W) { int c = 64; while (c < W) c <<= 1; return c; }
 // doubles of LDS per wave of k_knn_subset: the list, then max(hash table, ln-likelihoods + accumulation row)
 __host__ __device__ inline size_t fz_knn_subset_lds_doubles(int acc_stride, int W) {

@@ -569,9 +569,29 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
                 float2 pk = *reinterpret_cast<const float2*>(&qs[Rn][7]);
                 asm volatile("" : "+v"(l), "+v"(lj), "+v"(pk2), "+v"(pk.x), "+v"(pk.y));     // all loads in flight before anything is consumed
                 const unsigned long long before = __ballot(lane < k && (l < dn || (l == dn && lj < jn)));     // lexicographic (distance, index)
-                const int pos = __builtin_popcountll(before);
+                int pos = __builtin_popcountll(before);
+                if (k > 64) {
+                    // lists longer than the wave (64 < k <= FZ_KNN_KMAX; knn.py:190-193 takes any k): the rank over the further 64-entry
+                    // segments, then the shift from the top segment down -- a segment's entries are read by all of its lanes before any
+                    // of them is written one place up, and the place its last entry moves to belongs to the segment above, already moved
+                    for (int sg = 64; sg < k; sg += 64) {
+                        const int e = sg + lane;
+                        const double le = ldr[e < k ? e : 0];
+                        const int je = ljr[e < k ? e : 0];
+                        pos += __builtin_popcountll(__ballot(e < k && (le < dn || (le == dn && je < jn))));
+                    }
+                    if (pos < k) {
+                        for (int sg = (k - 1) & ~63; sg >= 64; sg -= 64) {
+                            const int e = sg + lane;
+                            const double le = ldr[e < k ? e : 0];
+                            const int je = ljr[e < k ? e : 0];
+                            if (e >= pos && e < k - 1) { ldr[e + 1] = le; ljr[e + 1] = je; }
+                            if (e == pos) { ldr[e] = dn; ljr[e] = jn; }
+                        }
+                    }
+                }
                 const bool ok = pos < k;                              // (wave-uniform) pos == k: the row's bar moved while draining
-                if (ok && lane >= pos && lane < k - 1) { ldr[lane + 1] = l; ljr[lane + 1] = lj; }
+                if (ok && lane >= pos && lane < k - 1) { ldr[lane + 1] = l; ljr[lane + 1] = lj; }     // (k > 64: lane 63 moves into the segment above)
                 if (ok && lane == pos) { ldr[lane] = dn; ljr[lane] = jn; }
                 if (ok) {
                     const double nk = (pos >= k - 1) ? dn : pk2;     // the new k-th distance
@@ -685,7 +705,8 @@ static __global__ __launch_bounds__(NWB * 64) void k_knn_mfma(const float* __res
         KMT(5);
         for (int R = 0; R < 16; ++R) {
             const int64_t i = __shfl(qi, R, 64);
-            if (i0 + R < N && lane < k) idx[(i * K + tree) * k + lane] = (Ld[R * kpad + lane] < bound2) ? Lj[R * kpad + lane] : M;
+            if (i0 + R < N)
+                for (int e = lane; e < k; e += 64) idx[(i * K + tree) * k + e] = (Ld[R * kpad + e] < bound2) ? Lj[R * kpad + e] : M;
         }
     }
     KMT(6);

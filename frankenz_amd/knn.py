@@ -187,8 +187,9 @@ class NearestNeighbors():
     def _search_setup(self, k, eps, lp_norm, distance_upper_bound):
         if lp_norm not in (1, 2, np.inf):
             raise NotImplementedError("Minkowski norms 1, 2 and inf are implemented on the GPU (got %r)" % (lp_norm,))
-        if k > 64 or self.K * k > 4096:
-            raise NotImplementedError("k <= 64 and K*k <= 4096 are required (got k=%d, K=%d)" % (k, self.K))
+        # (k > 64 is served by the Euclidean matrix-pipe search only: the library refuses it for the other norms / > 6 features)
+        if k > 256 or self.K * k > 4096:
+            raise NotImplementedError("k <= 256 and K*k <= 4096 are required (got k=%d, K=%d)" % (k, self.K))
         self.k = k
         self.eps = eps              # the search is exact; any eps >= 0 is honoured
         self.lp_norm = lp_norm

@@ -367,11 +367,14 @@ def test_search_switches_leave_the_neighbour_table_unchanged(switch, monkeypatch
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('K,k,mode', [(12, 50, 'B'), (33, 64, 'A'), (12, 50, 'C')])
+@pytest.mark.parametrize('K,k,mode', [(12, 50, 'B'), (33, 64, 'A'), (12, 50, 'C'),
+                                      (8, 65, 'A'), (5, 128, 'B'), (4, 129, 'A'), (16, 256, 'A'), (3, 200, 'C')])
 def test_knn_more_than_512_neighbours_per_object(K, k, mode):
     """knn.py:190-193 takes any k and K: K k = 600 and 2 112 neighbour slots per object (round 3 stopped at 512) -- the subset
     kernel's de-dup table and lists are sized per launch -- against the oracle: neighbour lists in first-appearance order, padded
-    fit rows, PDFs; mode C goes through the de-dup kernel + the fixed point on the subset."""
+    fit rows, PDFs; mode C goes through the de-dup kernel + the fixed point on the subset.  k = 65 ... 256 (rounds 1-3 and the
+    first half of round 4 stopped at 64 = one list entry per lane): the matrix-pipe search keeps such lists in 64-entry segments
+    (rank over all segments, shift from the top segment down); K k = 4 096 is the largest table."""
     from frankenz_amd import NearestNeighbors
     d, od = dicts()
     rs = np.random.RandomState(K * 100 + k)
@@ -395,3 +398,23 @@ def test_knn_more_than_512_neighbours_per_object(K, k, mode):
     np.testing.assert_allclose(p, rp, rtol=1e-7, atol=1e-13)
     np.testing.assert_allclose(le, rle, rtol=1e-9)
     np.testing.assert_allclose(lm, rlm, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_knn_long_lists_are_refused_off_the_matrix_pipe():
+    """k > 64 is served by the Euclidean matrix-pipe search; the other norms keep one list entry per lane and refuse loudly."""
+    from frankenz_amd import NearestNeighbors
+    d, _ = dicts()
+    rs = np.random.RandomState(3)
+    M, N, B = 600, 8, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 20; Ye = 0.02 * Y; Ym = np.ones((M, B))
+    X = Y[rs.choice(M, N)] + SDSS_SIGMA * rs.randn(N, B); Xe = np.tile(SDSS_SIGMA, (N, 1)); Xm = np.ones((N, B))
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.04)
+    nn = NearestNeighbors(Y, Ye, Ym, K=3, feature_map='identity', rstate=np.random.RandomState(5), verbose=False)
+    with pytest.raises(NotImplementedError):
+        nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=100, lp_norm=1, label_dict=d,
+                       verbose=False)
+    with pytest.raises(NotImplementedError):
+        nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=300, label_dict=d, verbose=False)
+    p = nn.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, rstate=np.random.RandomState(6), k=100, label_dict=d, verbose=False)
+    assert np.all(np.isfinite(p)) and nn.neighbors.shape == (N, 300)
