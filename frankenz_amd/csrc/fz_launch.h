@@ -95,6 +95,19 @@ int fz_launch_plane_rows_g(fz_ctx* c, const double* plane, const fz::KdeView& kv
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, c->stream, plane, M, c->d_kv.as<fz::KdeView>(), kv.acc_stride, n,
                        (int)M, ko->wt_thresh, ko->normalize, lmap, levid, pdfs);
     HIPCHK(hipGetLastError());
+#ifdef FZ_PLANE_STATS
+    {
+        unsigned long long h[16], z[16] = {0};
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(fz::fz_plstats), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fz::fz_plstats), z, sizeof z);
+        const double wr = h[1] ? (double)h[1] : 1.0;                 // wave-rows
+        fprintf(stderr, "PLSTATS k_plane_rows<%d,%d>: %llu waves, %.1f rows each | cycles per wave and row: wait for the row %.0f | maximum + post %.0f | "
+                        "barrier %.0f | clear + previous row's sums / ties %.0f | weigh %.0f | request + sums + post %.0f | epilogue (all waves) %.0f "
+                        "(waves with outputs: %.0f)\n", NW, E2, h[0], wr / (double)(h[0] ? h[0] : 1), h[2] / wr, h[3] / wr, h[4] / wr, h[5] / wr, h[6] / wr,
+                h[7] / wr, h[8] / wr, h[9] ? h[10] / (wr * (double)h[9] / (double)h[0]) : 0.0);
+    }
+#endif
     c->last_form = "k_plane_rows";
     return 0;
 }

@@ -78,6 +78,15 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
 
 typedef double plane_d4 __attribute__((ext_vector_type(4)));
 
+// development build (-DFZ_PLANE_STATS, tools/mainbuild.sh): wall-clock cycles of every wave of k_plane_rows by section, summed
+// over the launch and printed by the launcher (per wave and row) -- the attribution DESIGN 3.3 asks for
+#ifdef FZ_PLANE_STATS
+__device__ unsigned long long fz_plstats[16];
+#define PLT(i) do { const long long plt_ = (long long)clock64(); pltime[i] += plt_ - pllast; pllast = plt_; } while (0)
+#else
+#define PLT(i) do { } while (0)
+#endif
+
 // K steps (of four) of the convolution as a matrix product, see the epilogue of k_plane_rows
 __host__ __device__ inline int plane_conv_ksteps(int w2) { return (16 + w2 + 3) >> 2; }
 
@@ -175,6 +184,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     // post the sums of row i, and only then the EPILOGUE OF ROW i - 1 (ln-evidence by wave 0, convolution by the waves that own
     // outputs, store) while the other waves already wait for row i + 1: the epilogue runs under the memory latency of the next row
     // instead of in front of it.  Three histograms rotate (weighed / convolved / cleared); every exchange word has a copy per row parity.
+#ifdef FZ_PLANE_STATS
+    long long pltime[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pllast = (long long)clock64(), plrows = 0;
+#endif
     int64_t i = blockIdx.x;
     if (i < N) load_row(i);
     bool havep = false;                                                      // a previous row waits for its epilogue (block-uniform)
@@ -185,8 +197,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     while (true) {
         const bool have = i < N;                                             // block-uniform
         if (!have && !havep) break;
+        PLT(6);
         if (have) {
             row_wait();
+            PLT(0);
             // ---- per-wave maximum (nan never becomes the best: v_max_f64 returns the other operand) ----
             double m = -INFINITY;
             bool an = false;
@@ -200,7 +214,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             const int wf = (__any(an) ? 1 : 0) | (__any(fnl) ? 2 : 0);
             if (lane == 0) { s_max[par * NW + wave] = m; s_flag[par * NW + wave] = wf; }
         }
+        PLT(1);
         __syncthreads();                                                     // the row's one barrier
+        PLT(2);
         double* row = hist + hb * acc_stride;                                // row i (zero: cleared one row ago)
         double* rowp = hist + (hb == 0 ? 2 : hb - 1) * acc_stride;           // row i - 1: complete, convolved below
         {
@@ -259,6 +275,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 if (tid == 0) { s_late[par ^ 1] = 0.0; s_amb[par ^ 1] = 0; }   // this parity's next use lies behind the next barrier
             }
         }
+        PLT(3);
         // ---- row i: exact maximum, weights against it, evidence sum, histogram ----
         double mx = 0.0;
         int fl = 0;
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                     __builtin_amdgcn_sched_barrier(0);                       // two entries at a time (all E2 at once spill the row)
                 }
             }
+            PLT(4);
             // ---- the row is used up: the next one is requested now, and everything below touches LDS and registers only ----
             const int64_t inext = i + gridDim.x;
             if (inext < N) load_row(inext);
@@ -304,7 +322,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             ssel = wave_sum_dpp(ssel);
             if (lane == 0) { s_sum[par * 2 * NW + wave] = s; s_sum[par * 2 * NW + NW + wave] = ssel; }
         }
+        PLT(5);
         // ---- epilogue of row i - 1, under the latency of row i + 1 ----
+#ifdef FZ_PLANE_STATS
+        plrows += have ? 1 : 0;
+#endif
         if (havep) {
             const bool anynan = flp & 1, firstnan = flp & 2;
             if (wave == 0) {                                                 // ln-evidence: one wave, no tables (a table load would wait for the row in flight)
@@ -350,6 +372,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         par ^= 1;
         hb = (hb == 2) ? 0 : hb + 1;
     }
+#ifdef FZ_PLANE_STATS
+    PLT(6);
+    if (lane == 0) {
+        atomicAdd(&fz_plstats[0], 1ull); atomicAdd(&fz_plstats[1], (unsigned long long)plrows);
+        for (int u = 0; u < 7; ++u) atomicAdd(&fz_plstats[2 + u], (unsigned long long)pltime[u]);
+        if (wave * 256 < G) { atomicAdd(&fz_plstats[9], 1ull); atomicAdd(&fz_plstats[10], (unsigned long long)pltime[6]); }
+    }
+#endif
 }
 
 }  // namespace fz

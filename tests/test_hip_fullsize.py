@@ -218,3 +218,44 @@ def test_config4_knn_at_its_stated_million_objects():
         assert nn2.Nneighbors.min() >= 20 and nn2.Nneighbors.max() <= W
         np.testing.assert_allclose(p2, p[sub], rtol=1e-12, atol=1e-16); np.testing.assert_array_equal(lm2, lm[sub])
         np.testing.assert_allclose(le2, le[sub], rtol=1e-13, atol=1e-13)
+
+
+def test_config5_substitute_stack_and_population_likelihood_at_catalogue_scale():
+    """BASELINE configs[4] beyond the 2 000-object golden (g12): a catalogue-sized run of the same chain -- a TRAINING-SET fit
+    (per-model errors, 2 % of the objects' bands unobserved), fused PDFs, the stacked n(z) = sum_i pdf_i, the population
+    ln-likelihood and its per-object overlaps (samplers.py:60-80), one Gibbs assignment step (samplers.py:498-499) -- checked
+    through what does not need the reference at this size: the stack and the overlaps against NumPy on the GPU's own PDFs,
+    every object assigned exactly once and only where its posterior has support, shard invariance of the stack, and oracle
+    parity of the PDFs on a random sample against the full training set."""
+    from frankenz_amd import BruteForce, samplers
+    n, m = 200000, 20000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, seed=20261004, varying_errors=True, mask_frac=0.02)
+    d, od = dicts()
+    bf = BruteForce(Y, Ye, Ym)
+    p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, return_gof=True, save_fits=False,
+                                 verbose=False)
+    assert p.shape == (n, 701) and np.isfinite(p).all()
+    np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    stack = p.sum(axis=0)
+    nz = stack / stack.sum()
+    ll, ov = samplers.loglike_nz(nz, p, return_overlap=True)
+    want = p @ nz
+    np.testing.assert_allclose(ov, want, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(ll, np.sum(np.log(want)), rtol=1e-12)
+    # the stack of two halves computed alone (another launch geometry) is the stack
+    h = n // 2
+    pa = bf.fit_predict(X[:h].copy(), Xe[:h].copy(), Xm[:h].copy(), z, ze, label_dict=d, save_fits=False, verbose=False)
+    pb = bf.fit_predict(X[h:].copy(), Xe[h:].copy(), Xm[h:].copy(), z, ze, label_dict=d, save_fits=False, verbose=False)
+    np.testing.assert_allclose(pa.sum(axis=0) + pb.sum(axis=0), stack, rtol=1e-11, atol=1e-12)
+    # one assignment step of the hierarchical sampler: one draw per object, inside the support of pdf_i * nz
+    u = np.random.RandomState(9).rand(n)
+    counts, bins = samplers.nz_assign(nz, p, u=u, return_bins=True)
+    assert counts.sum() == n and counts.shape == (701,)
+    np.testing.assert_array_equal(np.bincount(bins, minlength=701), counts)
+    assert np.all(p[np.arange(n), bins] * nz[bins] > 0)
+    # oracle parity on a sample, against the FULL training set
+    pick = np.random.RandomState(2).choice(n, 60, replace=False)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
+    np.testing.assert_allclose(le[pick], rle, **EVID)
+    np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
