@@ -148,15 +148,17 @@ __device__ __forceinline__ double interp1(double x, const XP& xp, const FP& fp, 
 // ---- per-object statistics: one wave per object ----------------------------------------------
 // stats rows (each of length N): 0-3 mean{value,std,conf,risk}, 4-7 median, 8-11 mode, 12-15 best,
 // 16-19 low95, low68, high68, high95, 20 Monte-Carlo draw.
-#define FZ_SUM_MAXCH 64                                  // grid points per lane: G <= 4096
+// One CDF row of G doubles per wave in LDS: four waves per block up to G = 4 800, two up to 9 600, one up to 19 200 (the launcher
+// picks; pdf.py:899-1074 takes any grid -- beyond 19 200 points a row no longer fits the 160 KB).
+#define FZ_SUM_MAXG 19200
 static __global__ __launch_bounds__(256) void k_summarize(const double* __restrict__ pdfs, const double* __restrict__ risk,
                                                           int64_t N, int G, const double* __restrict__ grid,
                                                           const double* __restrict__ urand, const double* __restrict__ widths,
                                                           double wscale, int64_t ostride, double* __restrict__ stats) {
-    extern __shared__ double smem[];                    // [4][G] CDF rows
+    extern __shared__ double smem[];                    // [waves per block][G] CDF rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= N) return;
     double* cdf = smem + (size_t)wave * G;
     const double* p = pdfs + i * G;

@@ -71,6 +71,30 @@ def test_summarize_larger_stack_custom_kernel_and_window():
     np.testing.assert_allclose(a, b, rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize('G', [4800, 6000, 11000])
+def test_summarize_on_grids_beyond_4096_points(G):
+    """pdf.py:899-1074 takes any grid; rounds 1-3 stopped at 4 096 points (four CDF rows per block in LDS).  Two / one rows per
+    block serve up to 9 600 / 19 200 points: the statistics of sharp and of broad PDFs against the oracle."""
+    from frankenz_amd.pdf import pdfs_summarize
+    rs = np.random.RandomState(G)
+    N = 37
+    grid = np.linspace(0.0, 6.0, G)
+    mu = rs.uniform(0.3, 5.7, N)[:, None]; sg = rs.uniform(0.01, 0.8, N)[:, None]
+    pd = np.exp(-0.5 * ((grid[None, :] - mu) / sg) ** 2) + 0.2 * np.exp(-0.5 * ((grid[None, :] - (6 - mu)) / (0.3 * sg)) ** 2)
+    u = np.random.RandomState(9).rand(N)
+    a, b = pd.copy(), pd.copy()
+    got = flat(pdfs_summarize(a, grid, rstate=np.random.RandomState(9)))
+    want = flat(fo.pdfs_summarize(b, grid, urand=u))
+    risk = np.dot(b, fo.loss_matrix(grid, 'lorentz'))
+    srt = np.sort(risk, axis=1)
+    decisive = (srt[:, 1] - srt[:, 0]) > 1e-9 * np.abs(srt[:, 0])
+    assert decisive.mean() > 0.8
+    check(got[:, decisive], want[:, decisive], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(a, b, rtol=1e-14, atol=0)
+    with pytest.raises(NotImplementedError):
+        pdfs_summarize(np.ones((2, 20000)), np.linspace(0, 1, 20000))
+
+
 def test_loglike_nz_golden_and_device_stack():
     from conftest import DevArray
     from frankenz_amd.samplers import loglike_nz
