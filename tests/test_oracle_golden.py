@@ -386,15 +386,16 @@ def test_g13_nz_assign_law_of_the_oracle():
 
 
 def test_knn_limits_are_refused_loudly_where_the_reference_would_run():
-    """knn.py:190-193 takes any k; the GPU search keeps k <= 64 (a wave ranks a set's list) and K k <= 4096 (LDS of the subset kernel;
-    round 3: 512): beyond that the call must fail before any work, with the limits in the message -- never a silent truncation."""
+    """knn.py:190-193 takes any k; the GPU search keeps k <= 256 (sorted lists in 64-entry segments; until the middle of round 4: 64)
+    and K k <= 4096 (LDS of the subset kernel; round 3: 512): beyond that the call must fail before any work, with the limits in
+    the message -- never a silent truncation."""
     from frankenz_amd import NearestNeighbors
     rs = np.random.RandomState(3)
     Y = rs.lognormal(1, 1, (300, 5)); Ye = 0.05 * Y; Ym = np.ones_like(Y)
     X = Y[:4] + 0.1
-    for K, k in ((9, 65), (65, 64)):        # k > 64; K k = 4160 > 4096
+    for K, k in ((9, 257), (65, 64)):       # k > 256; K k = 4160 > 4096
         nn = NearestNeighbors(Y, Ye, Ym, K=K, feature_map='identity', rstate=np.random.RandomState(1), verbose=False)
-        with pytest.raises(NotImplementedError, match='k <= 64 and K\\*k <= 4096'):
+        with pytest.raises(NotImplementedError, match='k <= 256 and K\\*k <= 4096'):
             nn.fit(X, 0.1 * np.ones_like(X), np.ones_like(X), k=k, verbose=False)
-        with pytest.raises(NotImplementedError, match='k <= 64 and K\\*k <= 4096'):
+        with pytest.raises(NotImplementedError, match='k <= 256 and K\\*k <= 4096'):
             nn.fit_predict(X, 0.1 * np.ones_like(X), np.ones_like(X), np.zeros(300), np.ones(300), label_grid=np.arange(5.), k=k, verbose=False)
