@@ -162,6 +162,14 @@ __device__ __forceinline__ double wave_max_pos_hi(double v) {
     return __hiloint2double(mx(mx(a, b), mx(c, d)), 0);
 }
 
+// chi2 of the band-constant-variance algebra in two instructions per band (k_hist, below); 0 restores the exact-difference form
+#ifndef FZ_HIST_CHI2_2OP
+#define FZ_HIST_CHI2_2OP 1
+#endif
+#ifndef FZ_HIST_C2ZERO
+#define FZ_HIST_C2ZERO 1e-16
+#endif
+
 template <int TW>
 struct HistState {
     double S[TW];            // per lane, EXACT: sum of the weights
@@ -305,6 +313,25 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 for (int b = 0; b < BT; ++b) ob[o].x[b] = uniform_d(ob[o].x[b]);
             }
         }
+        // chi2 in TWO instructions per band where the variance does not depend on the model (the mode-Ai algebra, every band count): with
+        // s = sqrt(1 / var) and xs = x s, formed here once per object,  (x - y)^2 / var = d^2,  d = fma(-y, s, xs)  -- one rounding of
+        // x s instead of the exact difference: |d - (x - y) s| <= 2^-53 |x| s = 1.1e-16 S/N.  The one place where the exact difference
+        // matters is a model IDENTICAL to the object (a training-set self match): the reference gets chi2 = 0 -- weight 0 for every
+        // power > 0 -- and a chi2 of 1e-28 in its place would make that pair the best fit of an object nothing else fits.  So this form
+        // treats chi2 <= 1e-16 AS zero (C2ZERO below: the classifier's zero test, at no cost; one compare + select in the direct form):
+        // rounding cannot lift a self match above that for S/N < 4e7, and a genuine pair below it weighs < (1e-16 / k)^(k/2) of the
+        // mode (power 0: exp(-chi2 / 2) = 1 to the last bit either way).
+        constexpr bool C2OP = (SRC::LMODE == 1) && FZ_HIST_CHI2_2OP;
+        if constexpr (C2OP) {
+#pragma unroll
+            for (int o = 0; o < TW; ++o)
+#pragma unroll
+                for (int b = 0; b < BT; ++b) {
+                    ob[o].v[b] = sqrt(ob[o].v[b]);
+                    ob[o].x[b] = ob[o].x[b] * ob[o].v[b];
+                    if constexpr (BT > 16) ob[o].x[b] = uniform_d(ob[o].x[b]);        // (32-band records: back to the scalar file, see above)
+                }
+        }
         HistState<TW> hs;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
@@ -389,7 +416,14 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     for (int q = 0; q < MP; ++q)
 #pragma unroll
                         for (int o = 0; o < TW; ++o) {
-                            c2[q][o] = src.chi2_of(ob[o], m[q]);
+                            if constexpr (C2OP) {
+                                double c = 0.0;
+#pragma unroll
+                                for (int b = 0; b < BT; ++b) { const double d = fma(-m[q].y[b], ob[o].v[b], ob[o].x[b]); c = fma(d, d, c); }
+                                if constexpr (EXACT) c = (c <= FZ_HIST_C2ZERO) ? 0.0 : c;      // (the screen form makes this decision in its classifier)
+                                c2[q][o] = c;
+                            } else
+                                c2[q][o] = src.chi2_of(ob[o], m[q]);
                             if (TAIL) c2[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? c2[q][o] : 1e30;   // pad lanes: weight 0
                         }
                     if constexpr (EXACT) {
@@ -427,7 +461,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                                 tl[q][o] = fmaf((float)__float_as_int(cf), hk23, fmaf(cf, -0.72134752f, T0c));
                                 // chi2 == 0 (a training-set self match) has weight 0 for every power K > 0: its t must be -inf, not the -127 K / 2 the bit
                                 // trick gives -- a finite t would pass for the object's best weight when everything else lies far below it
-                                tl[q][o] = (cf != 0.f) ? tl[q][o] : tzero;
+                                // (two-instruction chi2: everything up to 1e-16 IS the zero, see C2OP; a nan stays a nan)
+                                tl[q][o] = (C2OP ? !(cf <= (float)FZ_HIST_C2ZERO) : (cf != 0.f)) ? tl[q][o] : tzero;
                                 if (TAIL) tl[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? tl[q][o] : -INFINITY;   // pad lanes: dropped whatever the bar
                             }
 #pragma unroll

@@ -1125,3 +1125,37 @@ def test_no_dimensionality_prior_on_the_power_zero_form(kw, monkeypatch):
             rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
         close(p0, rp, rtol=1e-7, atol=1e-13); close(lm0, rlm, rtol=1e-9); close(le0, rle, **EVID64)
         close(p0, p1, rtol=1e-7, atol=1e-13); close(lm0, lm1, rtol=1e-9); close(le0, le1, **EVID)
+
+
+@pytest.mark.parametrize('kw', [{}, {'ignore_model_err': True}])
+def test_self_match_of_an_object_nothing_else_fits(kw):
+    """The one-pass kernel forms chi2 as sum (xs - y s)^2 (two instructions per band: one rounding of x s instead of the exact
+    difference), so a training-set SELF MATCH comes out as ~1e-24 instead of the reference's exact 0 -- and chi2 = 0 means weight 0
+    under the dimensionality prior (pdf.py:88-93: (k/2 - 1) ln chi2).  Left alone, that pair would be the best fit by far of an
+    object whose nearest OTHER model sits at chi2 ~ 300 (weights ~e^-150): the kernel therefore treats chi2 <= 1e-16 as zero.
+    Objects copied from models, errors scaled so that the nearest other model is at chi2 = 300 / 30 / 3: PDFs, ln-max and
+    ln-evidence against the oracle, which sees the exact zero."""
+    from frankenz_amd import BruteForce
+    d, od = dicts()
+    rs = np.random.RandomState(404)
+    M, B = 4000, 5
+    Y = rs.lognormal(1., 1., size=(M, B)) * 10; Ye = np.tile(0.01 * SDSS5, (M, 1)); Ym = np.ones((M, B))
+    js = rs.choice(M, 12, replace=False)
+    X = Y[js].copy()
+    Xe = np.empty_like(X)
+    for n, j in enumerate(js):
+        c = np.sum(((Y[j] - Y) / SDSS5) ** 2, axis=1); c[j] = np.inf
+        Xe[n] = SDSS5 * np.sqrt(c.min() / (300., 30., 3.)[n % 3])
+    Xm = np.ones_like(X)
+    z = rs.uniform(0, 6, M); ze = np.full(M, 0.05)
+    p, (lm, le) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw,
+                                                    return_gof=True, save_fits=False, verbose=False)
+    rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    assert np.isfinite(rlm).all()                        # (the self match is not the reference's maximum: its ln-like is -inf)
+    close(lm, rlm, rtol=1e-11); close(le, rle, rtol=1e-11)
+    close(p, rp, rtol=1e-8, atol=1e-13)
+    # and the stored-plane route (exact-difference chi2) agrees
+    bf = BruteForce(Y, Ye, Ym)
+    bf.fit(X.copy(), Xe.copy(), Xm.copy(), lprob_kwargs=kw, verbose=False)
+    assert np.all(np.isneginf(bf.fit_lnlike[np.arange(len(js)), js]))
+    close(bf.predict(z, ze, label_dict=d, verbose=False), rp, rtol=1e-8, atol=1e-13)
