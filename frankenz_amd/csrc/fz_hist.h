@@ -322,7 +322,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         // rounding cannot lift a self match above that for S/N < 4e7, and a genuine pair below it weighs < (1e-16 / k)^(k/2) of the
         // mode (power 0: exp(-chi2 / 2) = 1 to the last bit either way).
         constexpr bool C2OP = (SRC::LMODE == 1) && FZ_HIST_CHI2_2OP;
-        if constexpr (C2OP) {
+        // The free scale with model errors ignored (LMODE == 2) in the same units: ys = y s per pair and band, then
+        // inter = sum xs ys, shape = sum ys ys, scale = inter / shape, d = fma(-scale, ys, xs), chi2 = fma(d, d, chi2) -- five
+        // instructions per band instead of six.  A model identical to the object still has xs == ys bit for bit, hence inter ==
+        // shape, scale == 1 and chi2 == 0 EXACTLY (no zero threshold here); the residual x - scale y cancels to rounding in either
+        // form, so the accuracy is that of the six-instruction form.
+        constexpr bool C2OPB = (SRC::LMODE == 2) && !SRC::SAFE && FZ_HIST_CHI2_2OP;
+        if constexpr (C2OP || C2OPB) {
 #pragma unroll
             for (int o = 0; o < TW; ++o)
 #pragma unroll
@@ -421,6 +427,25 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #pragma unroll
                                 for (int b = 0; b < BT; ++b) { const double d = fma(-m[q].y[b], ob[o].v[b], ob[o].x[b]); c = fma(d, d, c); }
                                 if constexpr (EXACT) c = (c <= FZ_HIST_C2ZERO) ? 0.0 : c;      // (the screen form makes this decision in its classifier)
+                                c2[q][o] = c;
+                            } else if constexpr (C2OPB) {
+                                double ys[BT], inter = 0.0, shape = 0.0;
+#pragma unroll
+                                for (int b = 0; b < BT; ++b) {
+                                    ys[b] = m[q].y[b] * ob[o].v[b];
+                                    inter = fma(ys[b], ob[o].x[b], inter);
+                                    shape = fma(ys[b], ys[b], shape);
+                                }
+                                double sc;
+                                if (!(shape > 1e-280 && shape < 1e280)) sc = inter / shape;       // shape == 0 (no usable band) -> nan / inf like NumPy
+                                else {
+                                    const double rc = rcp_nr<1>(shape);
+                                    sc = inter * rc;
+                                    sc = fma(fma(-sc, shape, inter), rc, sc);                     // residual correction: n / n == 1 exactly
+                                }
+                                double c = 0.0;
+#pragma unroll
+                                for (int b = 0; b < BT; ++b) { const double d = fma(-sc, ys[b], ob[o].x[b]); c = fma(d, d, c); }
                                 c2[q][o] = c;
                             } else
                                 c2[q][o] = src.chi2_of(ob[o], m[q]);
