@@ -124,7 +124,7 @@ extern "C" int fz_set_workspace_limit(fz_ctx* c, int64_t bytes) {
 // ---------------------------------------------------------------------------
 // flags: bit0 = some mask entry is 0, bit1 = some mask entry is neither 0 nor 1,
 // bit2 = some value is outside the range the reciprocal-based fast arithmetic accepts,
-// bit3 = the model errors of some band differ between models
+// bit3 = the model errors of some band differ between models, bit4 = some observed model flux is beyond 1e9
 __global__ void k_prep_models(const double* y, const double* ye, const double* ym, int64_t M, int64_t Mp,
                               int B, int BT, double* sy, double* sye2, double* sye, uint32_t* bits, int* flags,
                               double* rec0, int rw0, double* rec1, int rw1) {
@@ -144,6 +144,7 @@ __global__ void k_prep_models(const double* y, const double* ye, const double* y
             if (mk != 0.0) bt |= 1u << b; else fl |= 1;
             if (mk != 0.0 && mk != 1.0) fl |= 2;
             if (!(ve2 == 0.0 || (ve2 > 1e-30 && ve2 < 1e30)) || !(fabs(vy) < 1e30)) fl |= 4;
+            if (mk != 0.0 && !(fabs(vy) < 1e9)) fl |= 16;           // (the segmented kernel's bound on an unobserved object band's term, fz_hist.h)
         } else if (j >= M) { vy = 1.0; ve2 = 1.0; ve = 1.0; }
         sy[(int64_t)b * Mp + j] = vy;
         sye2[(int64_t)b * Mp + j] = ve2;
@@ -191,9 +192,13 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     if (fl & 2) return fail(-4, "models_mask must be binary (0/1)");
     c->M = M; c->Mp = Mp; c->B = B; c->BT = BT;
     c->mc_rec0_valid = c->mc_rec1_valid = false;
+    c->seg_state = 0; c->seg_rec0_valid = c->seg_rec1_valid = false;
+    c->h_mbits.resize((size_t)M);
+    FZCHK(copy_out(c, c->h_mbits.data(), c->d_mbits.p, (size_t)M * 4));
     c->models_masked = (fl & 1) || (BT != B);
     c->models_real_masked = (fl & 1) != 0;
     c->models_wild = (fl & 4) != 0;
+    c->models_big = (fl & 16) != 0;
     // band-constant model errors (zeros for a template grid, a common floor, the SURVEY 8d
     // configurations): xe^2 + ye^2 does not depend on the model, so it is formed once per object
     // and mode A runs on the kernels of mode Ai (see obj_vmode); FZ_NO_ERRCONST=1 disables this
@@ -348,6 +353,8 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
         }
     }
     c->label_mode = 1; c->label_M = M;
+    c->h_pos.assign(pos.begin(), pos.begin() + M); c->h_cls.assign(cls.begin(), cls.begin() + M);
+    c->seg_state = 0; c->seg_rec0_valid = c->seg_rec1_valid = false;
     return 0;
 }
 
@@ -432,6 +439,87 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (fl & 2) return fail(-3, "gauss_kde labels: a label's window lies wholly below the grid "
                                 "(the reference's negative-index slicing there is not reproduced)");
     c->G = G; c->label_mode = 2; c->label_M = M; c->mc_ok = false;
+    c->seg_state = 0; c->seg_rec0_valid = c->seg_rec1_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// segmented model layout of the one-pass kernel (fz_hist.h, SEG): pdf.py:76-87 with models_mask
+// ---------------------------------------------------------------------------
+// segment-ordered copy of the model records: row j' <- row perm[j'], pad slots (perm < 0) benign (y = ye^2 = 1)
+// and the masked bands of a model ZERO (flux and error): the mask-free arithmetic of the segmented kernel then finds d = 0 - 0 there
+static __global__ void k_seg_records(const double* __restrict__ in, const int* __restrict__ perm, const uint32_t* __restrict__ mbits, int64_t Ms,
+                                     int rw, int nval, int BT, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Ms * rw) return;
+    const int64_t j = e / rw; const int r = (int)(e - j * rw);
+    const int src = perm[j];
+    double v = src >= 0 ? in[(int64_t)src * rw + r] : (r < nval ? 1.0 : 0.0);
+    if (src >= 0 && r < nval && !((mbits[src] >> (r % BT)) & 1u)) v = 0.0;
+    out[e] = v;
+}
+int fz_segments(fz_ctx* c, bool rec0) {
+    if (c->seg_state < 0) return 1;
+    if (c->seg_state == 0) {
+        c->seg_state = -1;
+        const int64_t M = c->M;
+        if (c->label_mode != 1 || c->label_M != M || (int64_t)c->h_mbits.size() != M || (int64_t)c->h_cls.size() != M) return 1;
+        // dictionary classes present, in dictionary order (the ranks of the class-sorted stack, fz_labels_upload_dict)
+        std::vector<int32_t> rank((size_t)c->D, -1);
+        int32_t C = 0;
+        {
+            std::vector<char> present((size_t)c->D, 0);
+            for (int64_t j = 0; j < M; ++j) present[c->h_cls[j]] = 1;
+            for (int64_t d = 0; d < c->D; ++d) if (present[d]) rank[d] = C++;
+        }
+        if (C > 1 && !c->mc_ok) return 1;                        // (tables of the class-sorted stack: half-widths <= 63, G <= 768)
+        const int64_t W0 = C > 1 ? c->mc_w0 : c->w0;
+        if (c->G + 2 * W0 > 65535) return 1;                     // the candidate buffers hold 16-bit label indices
+        std::vector<int32_t> order((size_t)M);
+        for (int64_t j = 0; j < M; ++j) order[j] = (int32_t)j;
+        auto key = [&](int32_t j) { return ((uint64_t)(uint32_t)rank[c->h_cls[j]] << 32) | c->h_mbits[j]; };
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+        std::vector<uint32_t> smask; std::vector<int32_t> srank, sstart, perm, tag;
+        perm.reserve((size_t)M + 4096); tag.reserve((size_t)M + 4096);
+        for (int64_t a = 0; a < M;) {
+            int64_t b = a;
+            while (b < M && key(order[b]) == key(order[a])) ++b;
+            const int32_t sg = (int32_t)smask.size();
+            if (sg >= 16384) return 1;                           // (14 bits of the tag word)
+            smask.push_back(c->h_mbits[order[a]]); srank.push_back(rank[c->h_cls[order[a]]]); sstart.push_back((int32_t)perm.size());
+            for (int64_t k = a; k < b; ++k) { perm.push_back(order[k]); tag.push_back((int32_t)((c->h_pos[order[k]] + W0) | (sg << 16))); }
+            if (perm.size() % 64) {                                  // pad slots: sign bit; every slot of their group: bit 30 (the kernel's tile test reads one)
+                while (perm.size() % 64) { perm.push_back(-1); tag.push_back((int32_t)((uint32_t)(sg << 16) | 0x80000000u)); }
+                for (size_t k = perm.size() - 64; k < perm.size(); ++k) tag[k] |= 0x40000000;
+            }
+            a = b;
+        }
+        sstart.push_back((int32_t)perm.size());
+        const int32_t last = (int32_t)smask.size() - 1;
+        while (perm.size() % 1024) { perm.push_back(-1); tag.push_back((int32_t)((uint32_t)(last << 16) | 0xc0000000u)); }   // whole tiles (FZ_MAX_TILE)
+        const int64_t Ms = (int64_t)perm.size();
+        if (Ms > M + M / 4 + 4096) return 1;                     // mask patterns as many as models (wide band sets): padding would dominate
+        HIPCHK(hipSetDevice(c->device));
+        FZCHK(c->d_seg_perm.ensure((size_t)Ms * 4)); FZCHK(c->d_seg_tag.ensure((size_t)Ms * 4));
+        FZCHK(c->d_seg_mask.ensure(smask.size() * 4)); FZCHK(c->d_seg_rank.ensure(srank.size() * 4));
+        FZCHK(copy_in(c, c->d_seg_perm.p, perm.data(), (size_t)Ms * 4)); FZCHK(copy_in(c, c->d_seg_tag.p, tag.data(), (size_t)Ms * 4));
+        FZCHK(copy_in(c, c->d_seg_mask.p, smask.data(), smask.size() * 4)); FZCHK(copy_in(c, c->d_seg_rank.p, srank.data(), srank.size() * 4));
+        FZCHK(c->d_seg_start.ensure(sstart.size() * 4)); FZCHK(copy_in(c, c->d_seg_start.p, sstart.data(), sstart.size() * 4));
+        c->seg_Ms = Ms; c->seg_n = (int32_t)smask.size(); c->seg_nrank = C;
+        c->seg_rec0_valid = c->seg_rec1_valid = false;
+        c->seg_state = 1;
+    }
+    bool& valid = rec0 ? c->seg_rec0_valid : c->seg_rec1_valid;
+    if (!valid) {
+        const int rw = rec0 ? fz_rec_width(2 * c->BT) : fz_rec_width(c->BT);
+        DevBuf& dst = rec0 ? c->d_seg_rec0 : c->d_seg_rec1;
+        FZCHK(dst.ensure((size_t)c->seg_Ms * rw * 8));
+        const int64_t tot = c->seg_Ms * rw;
+        hipLaunchKernelGGL(k_seg_records, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (rec0 ? c->d_rec0 : c->d_rec1).as<double>(),
+                           c->d_seg_perm.as<int>(), c->d_mbits.as<uint32_t>(), c->seg_Ms, rw, rec0 ? 2 * c->BT : c->BT, c->BT, dst.as<double>());
+        HIPCHK(hipGetLastError());
+        valid = true;
+    }
     return 0;
 }
 
@@ -935,9 +1023,17 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
             // When the models themselves are unmasked, the (usually large) share of objects with
             // every band observed keeps the mask-free kernels: the chunk is split in two launches.
             bool done = false;
+            // real-catalogue inputs (pdf.py:76-87 with models_mask / per-model models_err): masked MODELS in any mode, or objects with
+            // unobserved bands against per-model errors -- the one-pass kernel on the segmented model layout (fz_hist.h, SEG); +1: the
+            // form does not apply (too many mask patterns, a KDE form it does not take ...) and the chunk goes on as before
+            if ((var == VAR_MASKED || var == VAR_FAST) && c->BT == c->B && !c->prior.tab && (c->models_real_masked || (var == VAR_MASKED && mode == 0))) {
+                const int r0 = run_fitpredict(c, mode, VAR_SEG, o->dim_prior, n, ko, d_lm, d_le, d_pdf);
+                if (r0 < 0) return r0;
+                done = (r0 == 0);
+            }
             // objects with unobserved bands, unmasked models, modes Ai / B: the one-pass kernel with per-object band counts takes the whole
             // chunk (masked and fully observed objects alike); where it does not apply (+1) the chunk is split as before
-            if (var == VAR_MASKED && !c->models_real_masked && mode != 0 && !c->prior.tab) {
+            if (!done && var == VAR_MASKED && !c->models_real_masked && mode != 0 && !c->prior.tab) {
                 const int r0 = run_fitpredict(c, mode, VAR_OBJMASK, o->dim_prior, n, ko, d_lm, d_le, d_pdf);
                 if (r0 < 0) return r0;
                 done = (r0 == 0);

@@ -74,7 +74,7 @@ struct fz_ctx {
 
     // models (BruteForce.__init__)
     int64_t M = 0, Mp = 0; int B = 0, BT = 0;
-    bool models_masked = false, models_real_masked = false, models_wild = false, models_err_const = false;
+    bool models_masked = false, models_real_masked = false, models_wild = false, models_err_const = false, models_big = false;
     int64_t mc_info[4] = {0, 0, 0, 0};   // fz_modec_info: ambiguous objects re-run, slowest object's iterations, path, block shape
     int mc_lnl_only = 0;           // mode C: the caller of run_modec wants the final ln-like plane only (request); set back to 0 by whoever cannot honour it
     double grid_step = 0.0;        // gauss_kde grid labels: spacing of an evenly spaced grid (checked on upload), else 0
@@ -92,6 +92,12 @@ struct fz_ctx {
     // class-sorted copy of the fused kernel's model records + tables (many dictionary widths; fz_kernels.h, MC)
     bool mc_ok = false, mc_rec0_valid = false, mc_rec1_valid = false; int32_t mc_gp = 0, mc_w0 = 0;
     DevBuf d_mc_tag, d_mc_perm, d_mc_width, d_mc_off, d_mc_norm, d_rec0p, d_rec1p;
+    // segmented model layout of the one-pass kernel (k_hist<..., SEG>: masked models, per-model errors against masked objects):
+    // records sorted by (dictionary class, mask pattern), segments padded to whole 64-model groups.  Built on first use from the host
+    // copies below (fz_segments); seg_state: 0 not built, 1 built, -1 this model / label set does not take the form
+    std::vector<uint32_t> h_mbits; std::vector<int32_t> h_pos, h_cls;
+    int seg_state = 0; int64_t seg_Ms = 0; int32_t seg_n = 0, seg_nrank = 0; bool seg_rec0_valid = false, seg_rec1_valid = false;
+    DevBuf d_seg_tag, d_seg_perm, d_seg_mask, d_seg_rank, d_seg_start, d_seg_rec0, d_seg_rec1;
     // per-chunk object buffers
     DevBuf d_sx, d_sxe, d_sxm;       // a host call's whole object set, staged once (fz_fit_predict)
     DevBuf d_rx, d_rxe, d_rxm, d_ox, d_ov, d_obits, d_oslv, d_flags;
@@ -114,7 +120,7 @@ struct fz_ctx {
 
     std::vector<DevBuf*> all_bufs() {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
-                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
+                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_seg_tag, &d_seg_perm, &d_seg_mask, &d_seg_rank, &d_seg_start, &d_seg_rec0, &d_seg_rec1, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_omap, &d_redo, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_kgbox, &d_ktbox, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kqperm, &d_kqcnt};
         for (auto& b : d_pl) v.push_back(&b);
@@ -216,6 +222,9 @@ inline int pick_var(fz_ctx* c, int obj_flags) {
     if (c->BT != c->B) return c->BT > 8 ? fz::VAR_PAD : fz::VAR_MASKED;
     return fz::VAR_FAST;
 }
+
+// segmented layout (frankenz_hip.hip): 0 built (records of the asked kind valid), +1 not applicable, < 0 error
+int fz_segments(fz_ctx* c, bool rec0);
 
 // ---- per-band-count launchers (fz_inst.hip, one translation unit per BT) ------
 #define FZ_DECL_BT(N)                                                                                     \

@@ -80,8 +80,10 @@ __device__ __forceinline__ double chi2_logpdf(double am1, double chi2, double lg
 enum { VAR_FAST = 0, VAR_MASKED = 1, VAR_SAFE = 2,
        VAR_PAD = 3,      // host-side only: tame, no REAL band masked, but the band count is padded up to 12 / 16 / 24 / 32 -- the one-pass kernel
                          // runs its mask-free form (pad bands are zeros and add nothing), every other kernel its masked variant
-       VAR_OBJMASK = 4 };// host-side only, a REQUEST: objects with unobserved bands against unmasked models in modes Ai / B -- try the one-pass
+       VAR_OBJMASK = 4,  // host-side only, a REQUEST: objects with unobserved bands against unmasked models in modes Ai / B -- try the one-pass
                          // kernel with per-object band counts (masked bands carry inverse variance 0); +1 = not applicable, nothing was launched
+       VAR_SEG = 5 };    // host-side only, a REQUEST: masked models, or unobserved object bands against per-model errors -- try the one-pass
+                         // kernel on the segmented model layout (fz_hist.h, SEG); +1 = not applicable, nothing was launched
 
 template <int BT, int MODE, int VAR>
 struct Phot {

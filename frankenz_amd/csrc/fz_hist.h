@@ -50,6 +50,12 @@ namespace fz {
 #ifndef FZ_HIST_MP
 #define FZ_HIST_MP 1             // 64-model groups per trip of the model loop
 #endif
+#ifndef FZ_HIST_SEG_NW0
+#define FZ_HIST_SEG_NW0 16       // segmented form with per-model errors: waves per block
+#endif
+#ifndef FZ_HIST_SEG_PFMAX
+#define FZ_HIST_SEG_PFMAX 12     // segmented form: band count + record values up to which the next record is requested ahead
+#endif
 #ifndef FZ_HIST_REFRESH
 #define FZ_HIST_REFRESH 32     // steps between two updates of the candidate bar (and flushes of the fp32 partial sums)
 #endif
@@ -116,6 +122,18 @@ __device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTa
     if (wp & 1) pw = pw * sqrt_nr(r);
     const double w = pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
     return (c2 < K + 1400.0) ? w : 0.0;
+}
+
+// ... and for the exact band counts (4-8 bands: powers 0 ... 3 and a half) with the reciprocal of k formed once per pattern: no loop,
+// no branch but the wave-uniform one around the square root; r^3.5 e^-700 cannot overflow, so the clamp's guard is not needed
+template <bool SMALL = false>
+__device__ __forceinline__ double hist_exactw_rt8(double c2, int wp, double K, double rK, const FastTabs& tb) {
+    if (wp == 0) return SMALL ? exp_small_tab(-0.5 * c2, tb.expt) : exp_clamped(-0.5 * c2, tb);      // wave-uniform branch
+    const double r = c2 * rK, r2 = r * r;
+    const int h = wp >> 1;
+    double pw = ((h & 1) ? r : 1.0) * ((h & 2) ? r2 : 1.0);
+    if (wp & 1) pw = pw * sqrt_nr(r);
+    return pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
 }
 
 // models per LDS tile by record width: two tiles, the histograms and the candidate buffers share 160 KB
@@ -186,7 +204,20 @@ struct HistState {
 // OBJK: the band count behind the power of chi2 is the OBJECT's (its observed bands; one object per wave, so it is wave-uniform):
 // band sets padded up to 12 / 16 / 24 / 32 bands, and objects with unobserved bands against unmasked models in modes Ai / B, where a
 // masked band carries inverse variance 0 (k_prep_objects) and adds exactly nothing to chi2 in the mask-free arithmetic.
-template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8)>
+//
+// SEG: the SEGMENTED model layout -- masked MODELS, and objects with unobserved bands against per-model errors (pdf.py:76-87 with
+// models_mask / per-model models_err: the shape of a real training catalogue).  N_dim = sum_b m_obj m_model is then a property of
+// the PAIR.  The kernel's copy of the model records is sorted by mask pattern (fz_build_segments: a handful of patterns at a few
+// per cent of missing bands), every pattern padded to whole 64-model groups, so that the pattern -- hence N_dim, the power of chi2,
+// the normalisation and which bands count -- is WAVE-UNIFORM per step and changes a few dozen times per pass.  At a change the
+// wave settles what waits in its buffer and re-derives its "effective object row" for the new pattern: a band that either side
+// masks gets inverse variance 0 (modes Ai / B: it then adds exactly nothing to chi2, inter and shape) or, with per-model
+// errors, the multiplier 0 in d = fma(-y, mk, x mk) (mk = 1: the exact difference x - y, as before; mk = 0: d = 0).  The reference
+// of every weight is the largest mode value over the patterns, LREF = max_s ln L_s(k_s); a pattern's weights carry the factor
+// f_s = L_s(k_s) / e^LREF <= 1 (in the classifier: an offset of t), so every bound of the scheme (w <= 1, "w > wt_thresh is
+// sufficient") holds across patterns.  An ambiguous entry records its N_dim (Cand::pad) and is settled by the reference's rule
+// with its own ln-like.  Objects for which some pattern leaves too few bands for a bounded likelihood go to the exact sweep.
+template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), bool SEG = false>
 __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __restrict__ kvp, int acc_stride, int64_t N, int M,
                                                    double wt_thresh, int normalize, Cand* __restrict__ amb, int64_t cap,
                                                    double* __restrict__ lmap, double* __restrict__ levid, double* __restrict__ pdfs,
@@ -194,6 +225,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     constexpr int TILE = hist_tile<SRC>(), RW = SRC::RW, TDR = RW * TILE, TD = TDR + TILE / 2, NT = NW * 64, OD = SRC::OBJ_DOUBLES;
     constexpr int WP = SRC::WPOW, BT = SRC::NB;
     static_assert(!OBJK || TW == 1, "per-object band counts: one object per wave");
+    static_assert(!SEG || (OBJK && SRC::NB <= 8), "segments: run-time band counts, 4-8 bands");
+    constexpr double SEG_VBIG = BT <= 5 ? 0x1p192 : (BT == 6 ? 0x1p160 : (BT == 7 ? 0x1p137 : 0x1p120));      // 2^(960 / BT): BT such terms multiply without overflow
+    constexpr int KOFF = SRC::LMODE == 2 ? 3 : 2;                       // power of chi2 = N_dim - KOFF (pdf.py:91-93 / 227-229)
     constexpr bool KRT = OBJK;                                          // run-time power (set per object below)
     int wpr = WP;
     double K = (double)WP;
@@ -212,6 +246,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     // the parked object rows are only read once, right after the first barrier of a round (into registers): in the screen form
     // they share the LDS of the wave's candidate buffer, which is empty then (all settled at the end of the previous round)
     __shared__ __attribute__((aligned(16))) double s_objs[EXACT ? NOBJ * OD : 2];
+    // SEG: the object's row as prepared (the effective row of a mask pattern is derived from it at every change of pattern)
+    __shared__ __attribute__((aligned(16))) double s_obj0[SEG ? NOBJ * OD : 2];
     static_assert(EXACT || TW * OD <= TW * CAP, "an object row must fit its candidate buffer");
     extern __shared__ double s_rows[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -229,9 +265,10 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         tbx.logt = nullptr; tbx.expt = s_tabs;
     }
     const KdeView kv = *kvp;
-    const int32_t* posw = kv.pos;
-    const int w0 = kv.w0;
+    const int32_t* posw = SEG ? kv.mc_tag : kv.pos;
+    const int w0 = SEG ? 0 : kv.w0;                                      // (a segment tag carries its histogram offset)
     double* objs = EXACT ? s_objs + wave * (TW * OD) : s_c2 + wave * (TW * CAP);
+    double* obj0 = s_obj0 + (SEG ? wave * (TW * OD) : 0);
     double* rows = s_rows + (size_t)wave * TW * acc_stride;
     double* rc2 = s_c2 + (EXACT ? 0 : wave * (TW * CAP));
     tag_t* rtag = s_tag + (EXACT ? 0 : wave * (TW * CAP));
@@ -262,8 +299,10 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         if constexpr (KRT) return (wpr == 0) ? fma(-0.5, c2, -lgq) : chi2_logpdf<true>(0.5 * K, c2, lgq, tb);      // (power 0: no x log x term)
         else return src.lnl_of_chi2(c2);
     };
+    double rK = 1.0;                                                    // SEG: 1 / K of the pattern in force
     auto exactw_tab = [&](double c2, const FastTabs& t, auto small) {
-        if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
+        if constexpr (SEG) return hist_exactw_rt8<decltype(small)::value>(c2, wpr, K, rK, t);
+        else if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
         else return hist_exactw<WP, decltype(small)::value>(c2, t);
     };
     double lref = uniform_d(lnl_c2(K));                           // ln L at the mode: the reference of every weight
@@ -278,7 +317,46 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             src.park_obj(omap ? (int64_t)omap[os] : os, objs + o * OD, lane);
         }
         for (int k = lane; k < TW * acc_stride; k += 64) rows[k] = 0.0;
-        if constexpr (OBJK) {
+        // SEG: state of the pattern in force (set by seg_switch below)
+        uint32_t obits = 0; double oslv = 0.0, fk = 1.0; int segcur = -1, ndcur = 0;
+        bool segbad = false;                                            // the pattern in force has no mode (power -1/2), see below
+        int nbadm = 0;                                                  // models in such patterns
+        // ln-like of a pair from its chi2 and its own N_dim (per lane): pdf.py:90-98 / 226-235
+        auto seg_lnl = [&](double c2, int nd) {
+            const bool dp = src.lp.dim_prior != 0;
+            const int wp = dp ? nd - KOFF : 0;
+            const double lg = dp ? src.lp.lgtab[nd] : 0.5 * ((double)nd * FZ_LN2PI + oslv);
+            const double xl = (wp == 0) ? 0.0 : (0.5 * (double)wp) * log_pos_t<true>(c2, tb);
+            return fma(-0.5, c2, xl) - lg;
+        };
+        if constexpr (SEG) {
+            const int64_t os = i0 < N ? i0 : N - 1;
+            const int64_t oi = omap ? (int64_t)omap[os] : os;
+            src.park_obj(oi, obj0, lane);
+            obits = (uint32_t)__builtin_amdgcn_readfirstlane((int)src.ov.bits[oi]);
+            oslv = uniform_d(src.ov.slv[oi]);
+            const bool dp = src.lp.dim_prior != 0;
+            // the reference of every weight: the largest value any pattern's likelihood takes at its mode (chi2 = k; power 0: chi2 = 0)
+            // Power -1/2 (one common band; two with the free scale): chi2^(-1/2) e^(-chi2/2) has no mode, its pairs are bounded by
+            // their own best only -- found by a look-ahead over those (few) models before the loop starts (below).  Less than
+            // that: the reference's own row is undefined (gammaln(0), pdf.py:92 / 228) -- the sweep reproduces whatever it gives.
+            double lr = -INFINITY; bool bad = false;
+            for (int sg = lane; sg < kv.seg_n; sg += 64) {
+                const int nd = __popc(obits & kv.seg_mask[sg]);
+                const int wp = dp ? nd - KOFF : 0;
+                bad |= wp < -1;
+                nbadm += (wp == -1) ? kv.seg_start[sg + 1] - kv.seg_start[sg] : 0;
+                const double lg = dp ? src.lp.lgtab[nd] : 0.5 * ((double)nd * FZ_LN2PI + oslv);
+                const double hw = 0.5 * (double)wp;
+                if (wp >= 0) lr = fmax(lr, wp > 0 ? fma(hw, log_pos((double)wp, tb), -hw) - lg : -lg);
+            }
+            nbadm = __builtin_amdgcn_readfirstlane((int)wave_sum((double)nbadm));
+            kok = __ballot(bad) == 0ull && nbadm <= (M >> 3);          // (an object whose every pattern is of that kind: the sweep)
+            lref = uniform_d(wave_max(lr));
+            float h_, t_; t_consts((double)BT, h_, t_, tmarg);       // (the classifier's margin of the largest power covers every pattern)
+            tmarg = uniform_f(tmarg);
+        }
+        if constexpr (OBJK && !SEG) {
             const int64_t os = i0 < N ? i0 : N - 1;
             const int nb = __builtin_amdgcn_readfirstlane(__popc(src.ov.bits[omap ? (int64_t)omap[os] : os]));   // observed bands (pad bits are 0)
             const int64_t oi = omap ? (int64_t)omap[os] : os;
@@ -328,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         // shape, scale == 1 and chi2 == 0 EXACTLY (no zero threshold here); the residual x - scale y cancels to rounding in either
         // form, so the accuracy is that of the six-instruction form.
         constexpr bool C2OPB = (SRC::LMODE == 2) && !SRC::SAFE && FZ_HIST_CHI2_2OP;
-        if constexpr (C2OP || C2OPB) {
+        if constexpr ((C2OP || C2OPB) && !SEG) {
 #pragma unroll
             for (int o = 0; o < TW; ++o)
 #pragma unroll
@@ -350,8 +428,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 
         // one candidate (exact chi2, label index, all lanes of `act`): evidence share, best chi2 on either
         // side of the mode, histogram add or ambiguous list
-        auto settle = [&](int o, bool act, double c2, int tag) {
-            const double w = act ? exactw_tab(c2, tbx, std::integral_constant<bool, !EXACT>{}) : 0.0;
+        // (badc: the entries may belong to a pattern without a mode -- only the group-by-group path of the segmented form and the finish
+        //  see those, so the model loop's copies of this code do not carry the general ln-like)
+        auto settle = [&](int o, bool act, double c2, int tag, auto badc) {
+            double w;
+            if (decltype(badc)::value && segbad) w = act ? exp_clamped(seg_lnl(c2, ndcur) - lref, tb) : 0.0;      // (wave-uniform, rare)
+            else w = act ? exactw_tab(c2, tbx, std::integral_constant<bool, !EXACT>{}) : 0.0;
+            if constexpr (SEG) w *= fk;                           // (the pattern's mode value relative to the reference)
             hs.Sc[o] += w;
             hs.wmx[o] = vmax_raw(hs.wmx[o], w);
             if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + tag + w0], w);
@@ -365,169 +448,298 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 // the list holds `cap` entries (the launcher sizes it well above what a well-fitted object needs, not at M): an
                 // object that would overflow it -- every model within the band of a poor best fit -- is handed to the exact sweep
                 if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
-                    if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                    if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                     hs.namb[o] += np;
                 } else hs.namb[o] = -1;                           // overflowed: nothing more is stored, the object goes to the sweep
             }
         };
         // settle the LAST (up to) 64 entries of object o's buffer with all lanes (their order does not matter: nothing has to move)
-        auto drain = [&](int o) {
+        auto drain = [&](int o, auto badc) {
             const int n = hs.pend[o] < 64 ? hs.pend[o] : 64;
             const int rest = hs.pend[o] - n;                      // < 64
             double c2 = rc2[o * CAP + rest + lane];
             int tag = (int)rtag[o * CAP + rest + lane];
             const bool act = lane < n;
-            settle(o, act, c2, tag);
+            settle(o, act, c2, tag, badc);
             hs.pend[o] = rest;
         };
+        // SEG: a group of another mask pattern begins: the pattern's power, normalisation, classifier constants and effective object
+        // row.  The candidate buffer is EMPTY here -- the step before a change settles everything (its entries' power and factor
+        // are the old pattern's; `flush` in step_body: the loop's own drain site, so that this rare code holds no second copy of the
+        // settle and leaves the registers of the model loop alone).
+        auto seg_switch = [&](int sw) {
+            const uint32_t jb = obits & kv.seg_mask[sw & 0x3fff];     // bands both sides observe (wave-uniform)
+            const int nd = __popc(jb);
+            const bool dp = src.lp.dim_prior != 0;
+            wpr = dp ? nd - KOFF : 0;
+            segbad = wpr == -1;
+            if (wpr < 0) wpr = 1;                                      // (below -1 kok is false: the object goes to the sweep; the arithmetic stays finite)
+            ndcur = nd;
+            K = uniform_d((double)wpr);
+            rK = uniform_d(wpr > 0 ? 1.0 / (double)wpr : 1.0);
+            float tm_;
+            t_consts(K, hk23, T0c, tm_);
+            lgq = uniform_d(dp ? src.lp.lgtab[nd] : 0.5 * ((double)nd * FZ_LN2PI + oslv));
+            const double dl = uniform_d(lnl_c2(K)) - lref;             // the pattern's mode value against the reference: <= 0
+            fk = uniform_d(exp_neg(dl, tb));
+            hk23 = uniform_f(hk23);
+            T0c = uniform_f(T0c + (float)(dl * 1.4426950408889634));
+            tzero = wpr > 0 ? -INFINITY : T0c;
+            if (segbad) {
+                // no classifier for a likelihood without a mode: every pair of the pattern is settled (t finite and far below anything,
+                // the bar at -inf while the pattern lasts), by its own ln-like against the reference
+                hk23 = 0.f; T0c = -1e30f; tzero = INFINITY; fk = 1.0;
+            }
+            if constexpr (!EXACT) hs.tthr[0] = segbad ? -INFINITY : wave_maxf_dpp(hs.tmax[0]) + (ldrop0 - 2.f * tmarg);
+            src.load_obj_lds(obj0, ob[0]);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                const bool on = (jb >> b) & 1u;
+                if constexpr (C2OP || C2OPB) { ob[0].v[b] = sqrt(ob[0].v[b]); ob[0].x[b] = ob[0].x[b] * ob[0].v[b]; }
+                // a band either side masks: inverse variance 0 (modes Ai / B: it adds exactly nothing to chi2, inter and shape); with
+                // per-model errors the VARIANCE term 2^(960 / BT) and flux 0 -- a masked MODEL band has y = ye^2 = 0 in the segment-ordered
+                // records, so d = 0 and the band adds exactly nothing; an unobserved OBJECT band adds y^2 / 2^192 (5 bands; 2^120 at 8)
+                // to a chi2 of order one: below its last bit for |y| < 1e20 (1e9), and the launcher declines model sets beyond that.
+                // (No multiplier per band: five more wave-uniform doubles did not fit the scalar file and spilled in the model loop.)
+                if constexpr (SRC::LMODE == 0) ob[0].v[b] = on ? ob[0].v[b] : SEG_VBIG;
+                else ob[0].v[b] = on ? ob[0].v[b] : 0.0;
+                ob[0].x[b] = on ? ob[0].x[b] : 0.0;
+            }
+            segcur = sw & 0x3fff;                                      // (without the pad-slots flag: a flagged group never passes for "the pattern in force")
+        };
 
-        auto run_tile = [&](const double* cur, double* nxt, int t, auto tailc) {
+        // chi2 of one pair from the wave's (effective) object row: the forms of the model loop, also used by the segmented form's
+        // look-ahead over the few patterns whose likelihood has no mode (below)
+        auto pair_chi2 = [&](const typename SRC::MR& mm, const typename SRC::OR& oo) -> double {
+                if constexpr (C2OP) {
+                    double c = 0.0;
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) { const double d = fma(-mm.y[b], oo.v[b], oo.x[b]); c = fma(d, d, c); }
+                    if constexpr (EXACT) c = (c <= FZ_HIST_C2ZERO) ? 0.0 : c;      // (the screen form makes this decision in its classifier)
+                    return c;
+                } else if constexpr (C2OPB) {
+                    double ys[BT], inter = 0.0, shape = 0.0;
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) {
+                        ys[b] = mm.y[b] * oo.v[b];
+                        inter = fma(ys[b], oo.x[b], inter);
+                        shape = fma(ys[b], ys[b], shape);
+                    }
+                    // shape == 0 (no usable band) -> nan / inf like NumPy: the IEEE division sits behind a WAVE-uniform branch (the empty
+                    // asm keeps the compiler from turning it into a select, which puts the division's ~25 instructions into every step:
+                    // mode B 64.4 -> 73.4 ms per 2.6e10 pairs when this code moved into a lambda)
+                    const bool odd = !(shape > 1e-280 && shape < 1e280);
+                    const double rc = rcp_nr<1>(shape);
+                    double sc = inter * rc;
+                    sc = fma(fma(-sc, shape, inter), rc, sc);                         // residual correction: n / n == 1 exactly
+                    if (__ballot(odd) != 0ull) {
+                        asm volatile("" ::: "memory");
+                        if (odd) sc = inter / shape;
+                    }
+                    double c = 0.0;
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) { const double d = fma(-sc, ys[b], oo.x[b]); c = fma(d, d, c); }
+                    return c;
+                } else {
+                    // (SEG with per-model errors: the same mask-free arithmetic -- a masked band sits in the effective row as a huge
+                    //  variance term and a zero flux, see seg_switch; chi2 up to C2ZERO is the exact zero of a self match)
+                    double c = src.chi2_of(oo, mm);
+                    if constexpr (SEG && SRC::LMODE == 0 && EXACT) c = (c <= FZ_HIST_C2ZERO) ? 0.0 : c;
+                    return c;
+                }
+        };
+        if constexpr (SEG) {
+            // look-ahead: the best ln-like among the pairs of the patterns without a mode (few models: two-band records against an
+            // object that misses one of them) joins the reference, so that every weight of the object stays <= 1
+            if (kok && nbadm > 0) {                                    // wave-uniform
+                const bool dp = src.lp.dim_prior != 0;
+                double lb = -INFINITY;
+                for (int s0 = 0; s0 < kv.seg_n; s0 += 64) {
+                    const int sg = s0 + lane;
+                    const bool isb = sg < kv.seg_n && dp && (__popc(obits & kv.seg_mask[sg < kv.seg_n ? sg : 0]) - KOFF == -1);
+                    unsigned long long bm = __ballot(isb);
+                    while (bm) {
+                        const int sb = s0 + __builtin_ctzll(bm);
+                        bm &= bm - 1;
+                        seg_switch(sb);
+                        const int j1 = kv.seg_start[sb + 1];
+                        for (int j = kv.seg_start[sb] + lane; j < j1; j += 64) {          // (whole 64-slot groups)
+                            typename SRC::MR mm;
+                            src.load_model_rec16(j, mm);
+                            double c2 = pair_chi2(mm, ob[0]);
+                            if constexpr (C2OP || SRC::LMODE == 0) c2 = (c2 <= FZ_HIST_C2ZERO) ? 0.0 : c2;
+                            const double l = seg_lnl(c2, ndcur);
+                            lb = fmax(lb, posw[j] < 0 ? -INFINITY : l);
+                        }
+                    }
+                }
+                lref = uniform_d(fmax(lref, wave_max(lb)));
+                kok = lref < INFINITY;                                 // (a chi2 of exactly 0 there: +inf in the reference, pdf.py:92)
+                segcur = -1;
+            }
+        }
+        // one 64-model group against the wave's objects, records and label words in registers.  SLOW: the group may hold pad slots of
+        // a segment (SEG, tiles in which the mask pattern changes)
+        constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
+        static_assert(!SEG || MP == 1, "segments: one group per trip");
+        auto step_body = [&](typename SRC::MR (&m)[MP], int (&ptag)[MP], int st, int t, auto tailc, auto slowc, bool flush) {
+            constexpr bool TAIL = decltype(tailc)::value, SLOW = decltype(slowc)::value;
+                double c2[MP][TW];
+#pragma unroll
+                for (int q = 0; q < MP; ++q)
+#pragma unroll
+                    for (int o = 0; o < TW; ++o) {
+                        c2[q][o] = pair_chi2(m[q], ob[o]);
+                        if (TAIL) c2[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? c2[q][o] : 1e30;   // pad lanes: weight 0
+                    }
+                if constexpr (EXACT) {
+                    const int j = t * TILE + st * 64 + lane;
+#pragma unroll
+                    for (int o = 0; o < TW; ++o) {
+                        // every pair in fp64; the running best (of the exact weights) bounds what can still be stacked
+                        const bool valid = (!TAIL || j < M) && (!SLOW || ptag[0] >= 0);     // (pad slots of a segment carry the sign bit)
+                        double w;
+                        if (SLOW && segbad) w = valid ? exp_clamped(seg_lnl(c2[0][o], ndcur) - lref, tb) : 0.0;
+                        else w = valid ? exactw_tab(c2[0][o], tbx, std::false_type{}) : 0.0;
+                        if constexpr (SEG) { w *= fk; ptag[0] &= 0xffff; }
+                        hs.S[o] += w;
+                        hs.Sc[o] = vmax_raw(hs.Sc[o], w);       // (EXACT: Sc holds the best weight seen: the bar of the ambiguous band, and ln-max at the end)
+                        if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag[0] + w0], w);
+                        const bool am = valid && !(w > thr_def) && (w >= wt_thresh * 0.999 * hs.Sc[o]);
+                        const unsigned long long mask = __ballot(am);
+                        if (mask) {
+                            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            const int np = __builtin_popcountll(mask);
+                            if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
+                                if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                                hs.namb[o] += np;
+                            } else hs.namb[o] = -1;
+                        }
+                    }
+                    if ((++hs.tick & 15) == 0) {
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) hs.Sc[o] = wave_max(hs.Sc[o]);
+                    }
+                } else {
+                    float tl[MP][TW];
+#pragma unroll
+                    for (int q = 0; q < MP; ++q)
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            const float cf = (float)c2[q][o];                         // chi2 >= 0 (inf: t = -inf; nan: nan, settled and found weightless)
+                            tl[q][o] = fmaf((float)__float_as_int(cf), hk23, fmaf(cf, -0.72134752f, T0c));
+                            // chi2 == 0 (a training-set self match) has weight 0 for every power K > 0: its t must be -inf, not the -127 K / 2 the bit
+                            // trick gives -- a finite t would pass for the object's best weight when everything else lies far below it
+                            // (two-instruction chi2: everything up to 1e-16 IS the zero, see C2OP; a nan stays a nan)
+                            tl[q][o] = ((C2OP || (SEG && SRC::LMODE == 0)) ? !(cf <= (float)FZ_HIST_C2ZERO) : (cf != 0.f)) ? tl[q][o] : tzero;
+                            if (TAIL) tl[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? tl[q][o] : -INFINITY;   // pad lanes: dropped whatever the bar
+                            if constexpr (SLOW) tl[q][o] = (ptag[q] < 0) ? -INFINITY : tl[q][o];                   // pad slots of a segment: likewise
+                        }
+#pragma unroll
+                    for (int q = 0; q < MP; ++q) {
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+                            // ONE compare: at or below the bar -> dropped (it cannot matter to an fp64 sum);
+                            // above it (or not a number: chi2 beyond fp32's range, settled like any other and found weightless) -> the buffer
+                            const bool le = tl[q][o] <= hs.tthr[o];
+                            const bool c = !le;
+                            asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[q][o]));   // (a nan operand yields the other one)
+                            // -> the object's buffer (ballot + mbcnt compaction); its fill level is a wave-uniform scalar
+                            const unsigned long long mask = __ballot(c);
+                            // (v_mbcnt adds its count to a base: the fill level)  < 64 wait when a group begins, a group adds at most 64: never past CAP
+                            const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, hs.pend[o]));
+#if !defined(FZ_DIAG_NOAPPEND)
+                            if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)ptag[q]; }
+#endif
+                            hs.pend[o] += __builtin_popcountll(mask);
+                        }
+                        if (++hs.tick == hs.next) {                               // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
+                            hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
+#pragma unroll
+                            for (int o = 0; o < TW; ++o) {
+                                const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
+                                hs.tmax[o] = mx;
+                                hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
+                                if constexpr (SEG) hs.tthr[o] = segbad ? -INFINITY : hs.tthr[o];
+                                // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
+                                // what still waits in the buffer only raises it)
+                                hs.wamb[o] = wave_max_pos_hi(hs.wmx[o]) * (wt_thresh * 0.999);
+                            }
+                        }
+#pragma unroll
+                        for (int o = 0; o < TW; ++o) {
+#if defined(FZ_DIAG_NODRAIN)
+                            if (hs.pend[o] >= DTHR) { hs.pend[o] -= 64; }
+#else
+                    if constexpr (SLOW) { const int lim = flush ? 1 : DTHR; while (hs.pend[o] >= lim) drain(o, std::true_type{}); }     // (flush: a change of pattern follows)
+                    else { while (hs.pend[o] >= DTHR) drain(o, std::false_type{}); }
+#endif
+                        }
+                    }
+                }
+        };
+        // slowc (SEG): the tile goes group by group through the code that can change the pattern; else it is taken to be "pure" (below)
+        auto run_tile = [&](const double* cur, double* nxt, int t, auto tailc, auto slowc) {
             constexpr bool TAIL = decltype(tailc)::value;
+            constexpr bool pure = !decltype(slowc)::value;
             if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave);
             if (work) {
                 const int32_t* tags = reinterpret_cast<const int32_t*>(cur + TDR);
                 // MP 64-model groups per trip: their chi2 chains and weights sit in one basic block (the appends, which
                 // branch, follow), and the next trip's records are requested before the current ones are used
-                constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
                 static_assert((TILE / 64) % MP == 0, "groups per trip must divide the tile");
-                constexpr bool PF = hist_prefetch<SRC>();
-                typename SRC::MR mn[PF ? MP : 1];
-                int tagn[MP];
-                if constexpr (PF) {
-#pragma unroll
-                    for (int q = 0; q < MP; ++q) {
-                        src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
-                        tagn[q] = tags[q * 64 + lane];
-                    }
-                }
-#pragma unroll
-                for (int st = 0; st < TILE / 64; st += MP) {
-                    typename SRC::MR m[MP];
-                    int ptag[MP];
-#pragma unroll
-                    for (int q = 0; q < MP; ++q) {
-                        if constexpr (PF) { m[q] = mn[q]; ptag[q] = tagn[q]; }
-                        else { src.template load_model_lds<TILE>(cur, (st + q) * 64 + lane, m[q]); ptag[q] = tags[(st + q) * 64 + lane]; }
-                        asm volatile("" : "+v"(ptag[q]));         // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
-                    }
-                    if (PF && st + MP < TILE / 64) {
+                // (SEG with per-model errors: the next group's record is not requested ahead -- with the pattern's state beside the object
+                //  row, a second copy of a 10-double record does not fit the register file: spills inside the loop, 2.7x slower)
+                constexpr bool PF = hist_prefetch<SRC>() && !(SEG && SRC::NB + SRC::NVAL > FZ_HIST_SEG_PFMAX);
+                if constexpr (pure) {
+                    typename SRC::MR mn[PF ? MP : 1];
+                    int tagn[MP];
+                    if constexpr (PF) {
 #pragma unroll
                         for (int q = 0; q < MP; ++q) {
-                            src.template load_model_lds<TILE>(cur, (st + MP + q) * 64 + lane, mn[q]);
-                            tagn[q] = tags[(st + MP + q) * 64 + lane];
+                            src.template load_model_lds<TILE>(cur, q * 64 + lane, mn[q]);
+                            tagn[q] = tags[q * 64 + lane];
                         }
                     }
-                    double c2[MP][TW];
 #pragma unroll
-                    for (int q = 0; q < MP; ++q)
-#pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-                            if constexpr (C2OP) {
-                                double c = 0.0;
-#pragma unroll
-                                for (int b = 0; b < BT; ++b) { const double d = fma(-m[q].y[b], ob[o].v[b], ob[o].x[b]); c = fma(d, d, c); }
-                                if constexpr (EXACT) c = (c <= FZ_HIST_C2ZERO) ? 0.0 : c;      // (the screen form makes this decision in its classifier)
-                                c2[q][o] = c;
-                            } else if constexpr (C2OPB) {
-                                double ys[BT], inter = 0.0, shape = 0.0;
-#pragma unroll
-                                for (int b = 0; b < BT; ++b) {
-                                    ys[b] = m[q].y[b] * ob[o].v[b];
-                                    inter = fma(ys[b], ob[o].x[b], inter);
-                                    shape = fma(ys[b], ys[b], shape);
-                                }
-                                double sc;
-                                if (!(shape > 1e-280 && shape < 1e280)) sc = inter / shape;       // shape == 0 (no usable band) -> nan / inf like NumPy
-                                else {
-                                    const double rc = rcp_nr<1>(shape);
-                                    sc = inter * rc;
-                                    sc = fma(fma(-sc, shape, inter), rc, sc);                     // residual correction: n / n == 1 exactly
-                                }
-                                double c = 0.0;
-#pragma unroll
-                                for (int b = 0; b < BT; ++b) { const double d = fma(-sc, ys[b], ob[o].x[b]); c = fma(d, d, c); }
-                                c2[q][o] = c;
-                            } else
-                                c2[q][o] = src.chi2_of(ob[o], m[q]);
-                            if (TAIL) c2[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? c2[q][o] : 1e30;   // pad lanes: weight 0
-                        }
-                    if constexpr (EXACT) {
-                        const int j = t * TILE + st * 64 + lane;
-#pragma unroll
-                        for (int o = 0; o < TW; ++o) {
-                            // every pair in fp64; the running best (of the exact weights) bounds what can still be stacked
-                            const bool valid = !TAIL || j < M;
-                            const double w = valid ? exactw_tab(c2[0][o], tbx, std::false_type{}) : 0.0;
-                            hs.S[o] += w;
-                            hs.Sc[o] = vmax_raw(hs.Sc[o], w);       // (EXACT: Sc holds the best weight seen: the bar of the ambiguous band, and ln-max at the end)
-                            if (w > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ptag[0] + w0], w);
-                            const bool am = valid && !(w > thr_def) && (w >= wt_thresh * 0.999 * hs.Sc[o]);
-                            const unsigned long long mask = __ballot(am);
-                            if (mask) {
-                                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                                const int np = __builtin_popcountll(mask);
-                                if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
-                                    if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
-                                    hs.namb[o] += np;
-                                } else hs.namb[o] = -1;
-                            }
-                        }
-                        if ((++hs.tick & 15) == 0) {
-#pragma unroll
-                            for (int o = 0; o < TW; ++o) hs.Sc[o] = wave_max(hs.Sc[o]);
-                        }
-                    } else {
-                        float tl[MP][TW];
-#pragma unroll
-                        for (int q = 0; q < MP; ++q)
-#pragma unroll
-                            for (int o = 0; o < TW; ++o) {
-                                const float cf = (float)c2[q][o];                         // chi2 >= 0 (inf: t = -inf; nan: nan, settled and found weightless)
-                                tl[q][o] = fmaf((float)__float_as_int(cf), hk23, fmaf(cf, -0.72134752f, T0c));
-                                // chi2 == 0 (a training-set self match) has weight 0 for every power K > 0: its t must be -inf, not the -127 K / 2 the bit
-                                // trick gives -- a finite t would pass for the object's best weight when everything else lies far below it
-                                // (two-instruction chi2: everything up to 1e-16 IS the zero, see C2OP; a nan stays a nan)
-                                tl[q][o] = (C2OP ? !(cf <= (float)FZ_HIST_C2ZERO) : (cf != 0.f)) ? tl[q][o] : tzero;
-                                if (TAIL) tl[q][o] = (t * TILE + (st + q) * 64 + lane < M) ? tl[q][o] : -INFINITY;   // pad lanes: dropped whatever the bar
-                            }
+                    for (int st = 0; st < TILE / 64; st += MP) {
+                        typename SRC::MR m[MP];
+                        int ptag[MP];
 #pragma unroll
                         for (int q = 0; q < MP; ++q) {
+                            if constexpr (PF) { m[q] = mn[q]; ptag[q] = tagn[q]; }
+                            else { src.template load_model_lds<TILE>(cur, (st + q) * 64 + lane, m[q]); ptag[q] = tags[(st + q) * 64 + lane]; }
+                            asm volatile("" : "+v"(ptag[q]));         // keeps the index read up here, beside the record's (sunk into the append, it made every step wait for the LDS there)
+                        }
+                        if (PF && st + MP < TILE / 64) {
 #pragma unroll
-                            for (int o = 0; o < TW; ++o) {
-                                // ONE compare: at or below the bar -> dropped (it cannot matter to an fp64 sum);
-                                // above it (or not a number: chi2 beyond fp32's range, settled like any other and found weightless) -> the buffer
-                                const bool le = tl[q][o] <= hs.tthr[o];
-                                const bool c = !le;
-                                asm("v_max_f32 %0, %1, %2" : "=v"(hs.tmax[o]) : "v"(hs.tmax[o]), "v"(tl[q][o]));   // (a nan operand yields the other one)
-                                // -> the object's buffer (ballot + mbcnt compaction); its fill level is a wave-uniform scalar
-                                const unsigned long long mask = __ballot(c);
-                                // (v_mbcnt adds its count to a base: the fill level)  < 64 wait when a group begins, a group adds at most 64: never past CAP
-                                const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, hs.pend[o]));
-#if !defined(FZ_DIAG_NOAPPEND)
-                                if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)ptag[q]; }
-#endif
-                                hs.pend[o] += __builtin_popcountll(mask);
+                            for (int q = 0; q < MP; ++q) {
+                                src.template load_model_lds<TILE>(cur, (st + MP + q) * 64 + lane, mn[q]);
+                                tagn[q] = tags[(st + MP + q) * 64 + lane];
                             }
-                            if (++hs.tick == hs.next) {                               // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
-                                hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
-#pragma unroll
-                                for (int o = 0; o < TW; ++o) {
-                                    const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
-                                    hs.tmax[o] = mx;
-                                    hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
-                                    // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
-                                    // what still waits in the buffer only raises it)
-                                    hs.wamb[o] = wave_max_pos_hi(hs.wmx[o]) * (wt_thresh * 0.999);
-                                }
+                        }
+                        step_body(m, ptag, st, t, tailc, std::false_type{}, false);
+                    }
+                } else {
+                    {
+                        // group by group; a group whose SUCCESSOR belongs to another pattern empties the buffer when it is done (flush),
+                        // so that the change finds nothing waiting.  The tile's first group may already be of a new pattern (the previous
+                        // tile could not know): an all-pad step in front (st = -1) does the flushing for it.  (The last group's successor
+                        // lies in the next tile, which is then not "pure" and starts with that step.)
+#pragma unroll 1
+                        for (int st = -1; st < TILE / 64; ++st) {
+                            typename SRC::MR m[MP];
+                            int ptag[MP];
+                            const int stc = st < 0 ? 0 : st;
+                            src.template load_model_lds<TILE>(cur, stc * 64 + lane, m[0]);
+                            ptag[0] = st < 0 ? (int)0x80000000 : tags[stc * 64 + lane];
+                            const int nxt = st + 1 < TILE / 64 ? (tags[(st + 1) * 64] >> 16) & 0x3fff : segcur;      // (wave-uniform read)
+                            if (st >= 0) {
+                                const int sw = (__builtin_amdgcn_readfirstlane(ptag[0]) >> 16) & 0x7fff;
+                                if ((sw & 0x3fff) != segcur) seg_switch(sw);     // a few dozen times per pass; nothing waits in the buffer
                             }
-#pragma unroll
-                            for (int o = 0; o < TW; ++o) {
-#if defined(FZ_DIAG_NODRAIN)
-                                if (hs.pend[o] >= DTHR) { hs.pend[o] -= 64; }
-#else
-                                while (hs.pend[o] >= DTHR) drain(o);
-#endif
-                            }
+                            const bool flush = __builtin_amdgcn_readfirstlane(nxt) != segcur;        // (segcur: this group's pattern by now)
+                            step_body(m, ptag, stc, t, tailc, std::true_type{}, flush);
                         }
                     }
                 }
@@ -536,10 +748,39 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             __syncthreads();
 #endif
         };
-        for (int t = 0; t < ntiles; t += 2) {
-            if (t + 1 < ntiles) run_tile(tileA, tileB, t, std::false_type{}); else run_tile(tileA, tileB, t, std::true_type{});
-            if (t + 1 < ntiles) {
-                if (t + 2 < ntiles) run_tile(tileB, tileA, t + 1, std::false_type{}); else run_tile(tileB, tileA, t + 1, std::true_type{});
+        if constexpr (!SEG) {
+            for (int t = 0; t < ntiles; t += 2) {
+                if (t + 1 < ntiles) run_tile(tileA, tileB, t, std::false_type{}, std::false_type{}); else run_tile(tileA, tileB, t, std::true_type{}, std::false_type{});
+                if (t + 1 < ntiles) {
+                    if (t + 2 < ntiles) run_tile(tileB, tileA, t + 1, std::false_type{}, std::false_type{}); else run_tile(tileB, tileA, t + 1, std::true_type{}, std::false_type{});
+                }
+            }
+        } else {
+            // SEG: a tile whose four groups all belong to the pattern in force and hold no pad slot -- all but a few per cent of them -- is
+            // "pure" and runs the plain loop.  Runs of pure tiles have a loop of their own (two per trip, A then B), so that the loop-carried
+            // registers of the model loop are reconciled with those of the group-by-group code only where a run ends, not after every
+            // tile (one loop with a branch per tile: ~60 register moves per tile).  The segment-ordered set is padded to whole tiles:
+            // there is no partial tile.  (Every wave stages and meets the barrier once per tile whichever way it takes.)
+            auto tile_pure = [&](const double* cur) -> bool {
+                if (!work) return true;
+                const int wv = (reinterpret_cast<const int32_t*>(cur + TDR)[(lane & (TILE / 64 - 1)) * 64] >> 16) & 0x7fff;      // (segment | pad-slots flag << 14) of group lane mod 4
+                return __ballot(wv != segcur) == 0ull && !segbad;          // (segcur never carries the flag; a pattern without a mode: group by group)
+            };
+            int t = 0;
+            while (t < ntiles) {
+                if (!(t & 1)) {
+                    while (t < ntiles) {
+                        if (!tile_pure(tileA)) break;
+                        run_tile(tileA, tileB, t, std::false_type{}, std::false_type{}); ++t;
+                        if (t >= ntiles || !tile_pure(tileB)) break;
+                        run_tile(tileB, tileA, t, std::false_type{}, std::false_type{}); ++t;
+                    }
+                    if (t >= ntiles) break;
+                }
+                // the tile that ended the run -- or the B tile after it, pure or not: back to the A, B rhythm
+                if (t & 1) run_tile(tileB, tileA, t, std::false_type{}, std::true_type{});
+                else run_tile(tileA, tileB, t, std::false_type{}, std::true_type{});
+                ++t;
             }
         }
 
@@ -552,7 +793,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 double* row = rows + o * acc_stride;
                 double wbest_run = 0.0;
                 if constexpr (!EXACT) {
-                    while (hs.pend[o] > 0) drain(o);
+                    while (hs.pend[o] > 0) drain(o, std::integral_constant<bool, SEG>{});
                 } else {
                     wbest_run = wave_max(hs.Sc[o]);
                 }
@@ -577,9 +818,17 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         const int k = c0 + lane;
                         const bool in1 = k < na;
                         const Cand e1 = cb[in1 ? k : 0];
-                        const double l1 = in1 ? lnl_c2(e1.lnl) : -INFINITY;
+                        double l1, w1;
+                        if constexpr (SEG) {
+                            // the entry's own N_dim (Cand::pad): power, normalisation, and its weight against the reference
+                            l1 = in1 ? seg_lnl(e1.lnl, e1.pad) : -INFINITY;
+                            w1 = exp_neg(l1 - lref, tb);
+                        } else {
+                            l1 = in1 ? lnl_c2(e1.lnl) : -INFINITY;
+                            w1 = exactw_tab(e1.lnl, tb, std::false_type{});
+                        }
                         const bool s1 = in1 && (exp_neg(l1 - le, tb) > thr);   // strict
-                        if (s1) unsafeAtomicAdd(&row[e1.j + w0], exactw_tab(e1.lnl, tb, std::false_type{}));
+                        if (s1) unsafeAtomicAdd(&row[e1.j + w0], w1);
                     }
                 }
                 if (lane == 0) {

@@ -89,6 +89,25 @@ int FZ_NAME(fz_fitpredict_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64
     PhotSrc<BT_, MODE_, VAR_> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
     return fz_launch_fitpredict(c, ph, n, M, ko, lmap, levid, pdfs);
 #endif
+#if FZ_EXACT_BT
+    if (var == VAR_SEG) {
+        // masked models / unobserved object bands against per-model errors: k_hist on the segmented model layout (mask-free arithmetic,
+        // the handed-back objects are swept by the masked variant); +1: not applicable, the caller takes the masked route
+        int r = 1;
+        switch (mode) {
+#define FZ_CALL_SEG(MODE_)                                                                                                       \
+            case MODE_: { PhotSrc<FZ_BT, MODE_, VAR_FAST> ph; ph.mv = model_view(c); ph.ov = obj_view(c); ph.lp = like_params(c, MODE_, dim_prior); \
+                          PhotSrc<FZ_BT, MODE_, VAR_MASKED> pm; pm.mv = ph.mv; pm.ov = ph.ov; pm.lp = ph.lp;                       \
+                          r = fz_launch_hist_seg(c, ph, pm, n, M, ko, lmap, levid, pdfs); } break;
+            FZ_CALL_SEG(0) FZ_CALL_SEG(1) FZ_CALL_SEG(2)
+#undef FZ_CALL_SEG
+            default: break;
+        }
+        return r < 0 ? r : (r == 0 ? 0 : 1);
+    }
+#else
+    if (var == VAR_SEG) return 1;
+#endif
 #if !defined(FZ_DEV_FAST)
     // (also: no dimensionality prior on mask-free data in modes Ai / B -- the power-0 form of the same kernel, pdf.py:94-98)
     const bool nodp_fast = !dim_prior && (var == VAR_FAST || var == VAR_PAD) && (mode == 1 || mode == 2) && !c->prior.tab;

@@ -235,6 +235,10 @@ struct KdeView {
     // half-width, kernel-table offset, and the edge-truncated mass per padded index [rank][mc_gp]
     const int32_t* mc_tag; const int32_t* mc_width; const int64_t* mc_off; const double* mc_norm;
     int32_t mc_gp, mc_w0;
+    // segmented model layout (k_hist<..., SEG>, fz_hist.h): the kernel's copy of the model records is sorted by (dictionary class,
+    // mask pattern) and every segment is padded to whole 64-model groups; mc_tag[j'] = (y_idx + mc_w0) | segment << 16 |
+    // (group holds pad slots) << 30 | (pad slot) << 31; per segment: the models' mask word and the rank of their dictionary class
+    const uint32_t* seg_mask; const int32_t* seg_rank; const int32_t* seg_start; int32_t seg_n, seg_nrank;      // seg_start[s .. s + 1]: the segment's slots
 };
 // HIST: every label shares one dictionary kernel -> accumulate w/norm at the label's
 // grid index (one LDS atomic per selected model), convolve once at the end.

@@ -355,11 +355,16 @@ double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 // exact: every weight in fp64 (the all-fp64 evidence, and the form for broad likelihoods)
 // OBJK / SWS: per-object band counts (fz_hist.h); the sweep over handed-back objects then runs on `sws`, the MASKED variant of
 // the same likelihood when objects may have unobserved bands (the mask-free arithmetic of `src` does not know N_dim per object)
-template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), class SWS = SRC>
+// SEG (segmented model layout): `src` / `kv` / `M` are the segment-ordered records, their view and padded length; the sweep runs on
+// the caller's own records: `swsp`, `kv_sweep`, `M_sweep`
+template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), class SWS = SRC, bool SEG = false>
 int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
-                     double* lmap, double* levid, double* pdfs, const SWS* swsp = nullptr) {
+                     double* lmap, double* levid, double* pdfs, const SWS* swsp = nullptr, const fz::KdeView* kv_sweep = nullptr,
+                     int64_t M_sweep = 0) {
     constexpr int SW = 4;
-    auto kern = fz::k_hist<SRC, TW, NW, EXACT, OBJK>;
+    auto kern = fz::k_hist<SRC, TW, NW, EXACT, OBJK, SEG>;
+    const int64_t Msw = kv_sweep ? M_sweep : M;
+    const fz::KdeView& kvs = kv_sweep ? *kv_sweep : kv;
     const size_t lds = (size_t)NW * TW * kv.acc_stride * 8;
     {
         hipFuncAttributes fa;
@@ -390,7 +395,7 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     // resident and fit the workspace (with per-object band counts a few per cent of a chunk can land there), at least one per CU
     auto sweep = fz::k_fused<SWS, 1, SW, false, true>;
     constexpr size_t TDB2 = (size_t)SWS::template tile_doubles<SWS::template tile_len<SW>()>();
-    const size_t lds2 = ((size_t)((SW + 1) / 2) * kv.acc_stride <= TDB2) ? 0 : (size_t)SW * kv.acc_stride * 8;
+    const size_t lds2 = ((size_t)((SW + 1) / 2) * kvs.acc_stride <= TDB2) ? 0 : (size_t)SW * kvs.acc_stride * 8;
     bool sweep_ok = false;
     int bps = 1;
     {
@@ -402,12 +407,13 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
             sweep_ok = true;
         }
     }
-    const size_t sweep_blk = (size_t)SW * M * sizeof(fz::Cand);
+    const size_t sweep_blk = (size_t)SW * Msw * sizeof(fz::Cand);
     bps = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(bps, 4), (int64_t)(c->ws_limit / (sweep_blk * c->cu_count))));
     const size_t sweep_ws = (size_t)bps * c->cu_count * sweep_blk;
     if (c->d_cand.ensure(std::max((size_t)blocks * NW * per_wave, sweep_ws)) != 0) return 1;
     FZCHK(c->d_kv.ensure(2 * sizeof(fz::KdeView)));
     HIPCHK(hipMemcpyAsync(c->d_kv.p, &kv, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_kv.as<fz::KdeView>() + 1, &kvs, sizeof(fz::KdeView), hipMemcpyHostToDevice, c->stream));
     FZCHK(c->d_redo.ensure(((size_t)n + 1) * sizeof(int)));
     HIPCHK(hipMemsetAsync(c->d_redo.p, 0, sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));          // kv is a stack object
@@ -418,7 +424,7 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
         SWS sws;
         if constexpr (std::is_same<SWS, SRC>::value) sws = src; else sws = *swsp;
         hipLaunchKernelGGL(sweep, dim3((unsigned)std::min<int64_t>((int64_t)bps * c->cu_count, (n + SW - 1) / SW)), dim3(SW * 64), lds2, c->stream, sws,
-                           c->d_kv.as<fz::KdeView>(), kv.acc_stride, n, (int)M, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), M,
+                           c->d_kv.as<fz::KdeView>() + 1, kvs.acc_stride, n, (int)Msw, ko->wt_thresh, ko->normalize, c->d_cand.as<fz::Cand>(), Msw,
                            lmap, levid, pdfs, c->d_redo.as<int>() + 1, (int*)nullptr, c->d_redo.as<int>());
     }
     HIPCHK(hipGetLastError());
@@ -467,6 +473,48 @@ int fz_launch_hist_objmask(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n,
         if constexpr (SRC::LMODE == 2) r = fz_launch_hist_g<SRC, 1, NWH, true, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
         else r = fz_launch_hist_g<SRC, 1, NWH, false, true, SWS>(c, src, kv, n, M, ko, lmap, levid, pdfs, &sws);
         if (r <= 0) c->last_form = SRC::LMODE == 2 ? "k_hist<exact> (per-object band counts)" : "k_hist<screen> (per-object band counts)";
+        return r;
+    }
+}
+
+// k_hist on the segmented model layout or nothing (+1): masked models (any mode), objects with unobserved bands against per-model
+// errors.  `src`: the mask-free variant (its records are replaced by the segment-ordered copy), `sws`: the masked one (sweep over
+// the handed-back objects, on the caller's own records).  FZ_HIST_SEG=0 (tests) keeps the masked kernels of k_fused.
+template <class SRC, class SWS>
+int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap, double* levid,
+                       double* pdfs) {
+    if constexpr (!(SRC::WPOW >= 1 && SRC::WPOW <= 6) || SRC::NB > 8) return 1;
+    else {
+        fz::KdeView kv0;
+        FZCHK(fz_kde_view(c, kv0));
+        if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_SEG") && atoi(getenv("FZ_HIST_SEG")) == 0)) return 1;
+        if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv0.kmode != fz::KDE_HIST || !kv0.normtab) return 1;
+        // without the dimensionality prior the ln-like of mode A carries sum_b ln(xe^2 + ye^2) of the PAIR (pdf.py:96-98): not a power-0 form
+        if (!src.lp.dim_prior && SRC::LMODE == 0) return 1;
+        if (SRC::LMODE == 0 && c->models_big) return 1;           // (fluxes beyond 1e9: the bound on an unobserved object band's term, fz_hist.h)
+        const int rs = fz_segments(c, SRC::LMODE == 0);
+        if (rs != 0) return rs;
+        fz::KdeView kv = kv0;
+        kv.mc_tag = c->d_seg_tag.as<int32_t>(); kv.seg_mask = c->d_seg_mask.as<uint32_t>(); kv.seg_rank = c->d_seg_rank.as<int32_t>();
+        kv.seg_start = c->d_seg_start.as<int32_t>(); kv.seg_n = c->seg_n; kv.seg_nrank = c->seg_nrank;
+        SRC s2 = src;
+        s2.mv.rec0 = c->d_seg_rec0.as<double>(); s2.mv.rec1 = c->d_seg_rec1.as<double>();
+        fz_exact_now() = false;
+        // direct form: the free scale always (fz_hist.h); broad likelihoods by the sampled share of pairs within the threshold (the
+        // sample's mask-free arithmetic is an estimate here, which is all the choice needs); FZ_NOLIST=1 / 0 forces / forbids
+        bool ex = SRC::LMODE == 2 || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
+        if (!ex) {
+            const char* e = getenv("FZ_NOLIST");
+            const int want = e ? atoi(e) : -1;
+            if (want < 0 && n >= 16384) ex = fz_nolist_probe<SRC>(c, src, kv0, n, M, ko) > 0.12;
+            else ex = want == 1;
+        }
+        int r;
+        constexpr int NWS = (SRC::LMODE == 0) ? FZ_HIST_SEG_NW0 : 16;      // waves per block (per-model errors: see FZ_HIST_SEG_NW0)
+        if (ex) r = fz_launch_hist_g<SRC, 1, NWS, true, true, SWS, true>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
+        else if constexpr (SRC::LMODE != 2) r = fz_launch_hist_g<SRC, 1, NWS, false, true, SWS, true>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
+        else r = 1;
+        if (r <= 0) c->last_form = ex ? "k_hist<exact> (segmented models)" : "k_hist<screen> (segmented models)";
         return r;
     }
 }

@@ -149,8 +149,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     // the data are used.  The compiler does not count these loads: row_wait() is the s_waitcnt, tied to every register of the row
     // (tests/test_abi.py checks the compiled code: nothing touches a row register between its request and the wait).
     const int last2 = M / 2 - 1;
+    // FZ_PLANE_COUNTED_LOADS (the build's fallback when the listing check fails, __graft_entry__.check_hand_scheduled): ordinary
+    // non-temporal loads the compiler counts and waits for itself -- slower (address registers, parts of the row may spill) but safe
+    // with any register allocation.
     auto load_row = [&](int64_t i) {
         const char* rb = reinterpret_cast<const char*>(plane + i * ld);
+#if defined(FZ_PLANE_COUNTED_LOADS)
+#pragma unroll
+        for (int e = 0; e < E2; ++e) {
+            const unsigned off = (unsigned)min(e * NT + tid, last2) * 16u;
+            l[e] = __builtin_nontemporal_load(reinterpret_cast<const fz_d2*>(rb + off));
+        }
+        return;
+#endif
         int t = tid;
         asm volatile("" : "+v"(t));                                          // offsets formed here, per row (hoisted, the E2 of them spill)
         const unsigned off0 = (unsigned)t * 16u;
@@ -167,10 +178,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     };
     auto row_wait = [&]() {
         static_assert(E2 == 5 || E2 == 10, "operand list below");
+#if defined(FZ_PLANE_COUNTED_LOADS)
+        if constexpr (false)
+#else
         if constexpr (E2 == 10)
+#endif
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7]), "+v"(l[8]), "+v"(l[9]));
+#if !defined(FZ_PLANE_COUNTED_LOADS)
         else
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]));
+#endif
 #pragma unroll
         for (int e = 0; e < E2; ++e)
             if (2 * (e + 1) * NT > M) {                                      // wave-uniform: only the entries the row's end falls into (or past)

@@ -162,69 +162,29 @@ def test_kde_args_follow_python_call_semantics():
 
 
 def test_register_allocation_of_the_hand_scheduled_kernels():
-    """k_plane_rows issues its row loads as inline asm into named registers and waits for them by hand: a spill of those values
-    would read registers before the data lands (advisor, round 3) -- the build keeps the compiler's resource report and this test
-    requires ZERO scratch for every instantiation; k_knn_mfma's scan state must stay in registers at 4 waves per SIMD (a lambda
-    inlined three times once cost it its occupancy: 27 -> 72 ms)."""
+    """k_plane_rows issues its row loads as inline asm into named registers and waits for them by hand: a spill of those values, or
+    a register copy between the request and the wait, would read registers before the data lands (advisor, rounds 3 and 4);
+    k_knn_mfma's scan state must stay in registers at 4 waves per SIMD (a lambda inlined three times once cost it its occupancy:
+    27 -> 72 ms).  The checks live in the BUILD (`__graft_entry__.check_hand_scheduled`, run by build() and tools/mainbuild.sh, which
+    falls back to compiler-counted loads or fails): this test only asserts that the shipped library passed them."""
     import __graft_entry__ as ge
     ge.build()
-    if not os.path.exists(ge.RESOURCES):
+    if not os.path.exists(ge.RESOURCES) or not os.path.exists(ge.PLANE_ISA):
         ge.build(force=True)
-    txt = open(ge.RESOURCES).read()
-    blocks = re.split(r'remark: Function Name: ', txt)[1:]
-    seen = {'k_plane_rows': 0, 'k_knn_mfma': 0}
-    for b in blocks:
-        name = b.split(' ', 1)[0]
-        get = lambda key: int(re.search(key + r': (\d+)', b).group(1))
-        if 'k_plane_rows' in name:
-            seen['k_plane_rows'] += 1
-            assert get(r'ScratchSize \[bytes/lane\]') == 0 and get('VGPRs Spill') == 0, name
-        if 'k_knn_mfma' in name and 'Li1ELi5E' in name:           # the default instantiation (one wave per block, k <= 20)
-            seen['k_knn_mfma'] += 1
-            assert get(r'ScratchSize \[bytes/lane\]') == 0 and get(r'Occupancy \[waves/SIMD\]') >= 4, name
-    assert seen['k_plane_rows'] >= 3 and seen['k_knn_mfma'] >= 1, seen
+    assert ge.check_hand_scheduled() == []
 
 
-def test_nothing_touches_a_row_register_of_k_plane_rows_while_its_load_is_in_flight():
-    """The row loads of k_plane_rows are inline asm the compiler does not count (`global_load_dwordx4 ... nt`), waited for by a
-    hand-placed `s_waitcnt vmcnt(0)`.  Zero scratch (the test above) is necessary, not sufficient: a register COPY of an entry
-    between the two reads the register before the data lands just the same -- round 4 saw both when the loads were moved into
-    the weighing loop (`scratch_store_dwordx4 v[2:5]` on the line after `global_load_dwordx4 v[2:5]`; a second register set with
-    a copy at the loop's end).  The build keeps the kernel's machine code; here every instruction in layout order between a row
-    load and the next full wait is checked for operands inside the registers being loaded."""
+def test_the_listing_check_catches_a_touched_row_register(tmp_path, monkeypatch):
+    """the checker itself: a listing with a scratch store of a row register between its load and the wait must be flagged"""
     import __graft_entry__ as ge
     ge.build()
-    if not os.path.exists(ge.PLANE_ISA):
-        ge.build(force=True)
-    vreg = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
-    nfun = nload = 0
-    pending, fun = set(), None
-    for line in open(ge.PLANE_ISA):
-        code = line.split(';')[0].strip()
-        if line.startswith('_ZN2fz12k_plane_rows'):
-            fun, pending = line.split(':')[0], set()
-            nfun += 1
-            continue
-        if not code or code.startswith('.') or code.endswith(':'):
-            continue
-        regs = set()
-        for m in vreg.finditer(code):
-            if m.group(1) is not None:
-                regs.add(int(m.group(1)))
-            else:
-                regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
-        if code.startswith('global_load_dwordx4') and code.endswith(' nt'):
-            dst = vreg.search(code)
-            dreg = set(range(int(dst.group(2)), int(dst.group(3)) + 1))
-            addr = regs - dreg if code.count('v[') == 1 else set()
-            assert not (addr & pending), (fun, code)
-            # (a second request into the same registers is not flagged: the in-row and end-of-row forms of one entry's request sit in
-            #  exclusive branches, one after the other in layout order)
-            pending |= dreg
-            nload += 1
-            continue
-        if code.startswith('s_waitcnt') and 'vmcnt(0)' in code:
-            pending = set()
-            continue
-        assert not (regs & pending), (fun, code, sorted(regs & pending))
-    assert nfun >= 3 and nload >= 3 * 2 * 5, (nfun, nload)
+    txt = open(ge.PLANE_ISA).read()
+    if os.path.exists(ge.PLANE_ISA + ".counted"):
+        pytest.skip("this build runs k_plane_rows with compiler-counted loads")
+    m = re.search(r'(global_load_dwordx4 (v\[\d+:\d+\]),[^\n]* nt\n)', txt)
+    assert m
+    bad = txt.replace(m.group(1), m.group(1) + "\tscratch_store_dwordx4 off, %s, off offset:16\n" % m.group(2), 1)
+    f = tmp_path / "k.s"
+    f.write_text(bad)
+    monkeypatch.setattr(ge, "PLANE_ISA", str(f))
+    assert any('touches' in p for p in ge.check_hand_scheduled())

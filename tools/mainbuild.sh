@@ -10,7 +10,11 @@ if [ "$OUT" = libfrankenz_hip.so ]; then
   /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage "$@" -c "$PWD/frankenz_hip.hip" -o frankenz_hip.o 2> kernel_resources.txt || { tail -30 kernel_resources.txt; exit 1; }
   O=frankenz_hip.o
   /opt/rocm/bin/hipcc $F "$@" --cuda-device-only -S frankenz_hip.hip -o kernel_isa_plane_rows.s.all 2>/dev/null
-  (cd ../.. && python3 -c "import __graft_entry__ as g; g._keep_plane_isa()")
+  (cd ../.. && python3 -c "
+import __graft_entry__ as g, sys
+g._keep_plane_isa()
+p = g.check_hand_scheduled()
+if p: sys.exit('mainbuild: the hand-scheduled kernels failed their checks (run __graft_entry__.build(force=True) for the fallback):\n  ' + '\n  '.join(p))")
 else
   O=/tmp/fz_main_$$.o
   /opt/rocm/bin/hipcc $F "$@" -c frankenz_hip.hip -o $O
