@@ -120,7 +120,7 @@ def cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
     """the same loop on every host core (one process each, the objects split in blocks);
     spawned BEFORE this process touches the GPU."""
     import multiprocessing as mp
-    ncpu = min(os.cpu_count() or 1, 32)             # bounded: start-up of more workers dominates the run
+    ncpu = os.cpu_count() or 1                      # SURVEY 8d: every host core (the count is printed)
     per = max(1, min(len(X) // ncpu, 4096))
     jobs = [(Y, Ye, Ym, X[i * per:(i + 1) * per], Xe[i * per:(i + 1) * per], Xm[i * per:(i + 1) * per], z, ze, kw,
              budget_s) for i in range(ncpu)]
@@ -133,6 +133,141 @@ def cpu_baseline_all(Y, Ye, Ym, X, Xe, Xm, z, ze, kw, budget_s):
     return {"value": rate * len(Y), "unit": "evals/s", "pdfs_per_s": rate, "cores": ncpu, "kind": "port", "cpu": cpu_model(),
             "sample": "%d objects x %d models over %d processes, ~%.0f s each (wall %.1f s incl. start-up)"
                       % (nobj, len(Y), ncpu, budget_s, wall)}
+
+
+def _sub(fn):
+    """a sub-record of the default line: the measurement, or what went wrong (the headline never depends on it)"""
+    try:
+        return fn()
+    except Exception as e:           # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def sub_planes_predict(eng, dev, torch, pd, steps=3):
+    """BASELINE configs[1]: 1e5 objects x 1e4 models x 5 bands, materialising BruteForce.fit (lnlike + chi2 planes: HBM-write bound,
+    16 B per eval) and BruteForce.predict from the stored plane (8 B per eval read once)."""
+    from frankenz_amd.engine import kde_opts, like_opts
+    N, M = 100000, 10000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101, 5, 1.0)
+    eng.upload_models(Y, Ye, Ym)
+    eng.set_labels(z, ze, label_dict=pd)
+    dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
+    d_lnl = torch.empty((N, M), dtype=torch.float64, device=dev)
+    d_chi2 = torch.empty((N, M), dtype=torch.float64, device=dev)
+    d_pdf = torch.empty((N, pd.Ngrid), dtype=torch.float64, device=dev)
+    d_lm = torch.empty(N, dtype=torch.float64, device=dev); d_le = torch.empty(N, dtype=torch.float64, device=dev)
+    opts, ko = like_opts({}), kde_opts({"wt_thresh": 1e-3})
+    out = {}
+    eng.fit(dX, dXe, dXm, opts, d_lnl, d_chi2, n=N); eng.sync(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.fit(dX, dXe, dXm, opts, d_lnl, d_chi2, n=N)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    tm = eng.timing()
+    ms = tm["ms_planes"] / max(tm["n_planes"], 1)
+    gbs = N * M * 16 / (max(tm["n_planes"], 1) / steps) / (ms * 1e-3) / 1e9
+    out["planes"] = {"workload": "BASELINE configs[1]: BruteForce.fit, %d x %d x 5, lnlike + chi2 planes" % (N, M), "value": N * M / dt,
+                     "unit": "evals/s", "ms_per_step": dt * 1e3,
+                     "roofline": {"bound": "hbm", "kernel": "k_planes", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS, "bytes_per_eval": 16, "avg_launch_ms": ms}}
+    eng.predict_logwt(d_lnl, ko, d_pdf, d_lm, d_le, n=N); eng.sync(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.predict_logwt(d_lnl, ko, d_pdf, d_lm, d_le, n=N)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    tm = eng.timing()
+    ms = (tm["ms_stats"] + tm["ms_kde"] + tm["ms_fused"]) / steps
+    gbs = N * M * 8 / (ms * 1e-3) / 1e9
+    out["predict"] = {"workload": "BruteForce.predict(logwt=fit_lnprob): %d x %d plane -> %d PDFs" % (N, M, N), "value": N / dt,
+                      "unit": "PDFs/s", "ms_per_step": dt * 1e3,
+                      "roofline": {"bound": "hbm", "kernel": eng.last_form(), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs / HBM_PEAK_GBS, "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}
+    return out
+
+
+def sub_modec(eng, dev, torch, pd, steps=2):
+    """free scale WITH model errors (pdf.py:196-223): the fixed point's iteration count is data dependent, SURVEY 8d asks for evals/s
+    and the iterations, no roofline fraction"""
+    from frankenz_amd.engine import kde_opts, like_opts
+    N, M = 20000, 10000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101, 5, 1.0)
+    Ye = Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape)
+    eng.upload_models(Y, Ye, Ym)
+    eng.set_labels(z, ze, label_dict=pd)
+    dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
+    d_pdf = torch.empty((N, pd.Ngrid), dtype=torch.float64, device=dev)
+    d_lm = torch.empty(N, dtype=torch.float64, device=dev); d_le = torch.empty(N, dtype=torch.float64, device=dev)
+    opts, ko = like_opts(MODES["C"]), kde_opts({"wt_thresh": 1e-3})
+    eng.fit_predict_prior(dX, dXe, dXm, opts, ko, None, d_pdf, d_lm, d_le, n=N); eng.sync(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.fit_predict_prior(dX, dXe, dXm, opts, ko, None, d_pdf, d_lm, d_le, n=N)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    tm = eng.timing()
+    info = eng.modec_info()
+    return {"workload": "mode C (free scale with model errors): %d x %d x 5, fused fit_predict" % (N, M), "value": N * M / dt, "unit": "evals/s",
+            "ms_per_step": dt * 1e3, "iterations_of_the_slowest_object": tm["n_modec"] / steps - 2, "modec_info": [int(v) for v in info],
+            "note": "evals/s counts each (object, model) pair once, whatever its iteration count"}
+
+
+def sub_knn(dev, torch, pd, local, steps=2):
+    """BASELINE configs[3] slice: NearestNeighbors.fit_predict(save_fits=False), K = 25 Monte-Carlo feature sets, k = 20, 1e5 objects x
+    1e5 models, device resident.  The roofline figure is the matrix pipe's: the exact search multiplies 64-model tiles of fp32
+    features (padded to 8) against 16-query tiles, 2 x 8 flops per (query, model) it LOOKS at -- it skips tiles its k-d boxes exclude,
+    so `tiles_frac_of_exhaustive` < 1 is pruning, not idleness; `achieved` counts the exhaustive scan's flops over the search time."""
+    from frankenz_amd import NearestNeighbors
+    from frankenz_amd.engine import get_engine
+    N, M, Kt, kk = 100000, 100000, 25, 20
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101, 5, 1.0)
+    fk = dict(skynoise=SDSS_SIGMA, zeropoints=10 ** (0.4 * 23.9))
+    nn = NearestNeighbors(Y, Ye, Ym, K=Kt, feature_map="luptitude", fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
+    nn._device = local
+    q = nn._query_features(X, Xe, np.random.RandomState(2))
+    dQ = torch.from_numpy(q).to(dev)
+    dX, dXe, dXm = (torch.from_numpy(a).to(dev) for a in (X, Xe, Xm))
+    prep = nn.prepare_fit_predict(z, ze, label_dict=pd, kde_kwargs={"wt_thresh": 1e-3}, lprob_kwargs={}, k=kk)
+    d_pdf = torch.empty((N, pd.Ngrid), dtype=torch.float64, device=dev)
+    d_lm = torch.empty(N, dtype=torch.float64, device=dev); d_le = torch.empty(N, dtype=torch.float64, device=dev)
+    eng = get_engine(local)
+    prep.run(dX, dXe, dXm, out=(d_pdf, d_lm, d_le), query_features=dQ); eng.sync(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prep.run(dX, dXe, dXm, out=(d_pdf, d_lm, d_le), query_features=dQ)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    tm = eng.timing()
+    ms_knn = tm["ms_knn"] / steps
+    flops = 2.0 * 8 * Kt * N * M                      # exhaustive scan, fp32 features padded to 8
+    s = d_pdf[:4096].sum(dim=1)
+    return {"workload": "BASELINE configs[3] slice: NearestNeighbors.fit_predict(save_fits=False), %d objects x %d models, K=%d k=%d" % (N, M, Kt, kk),
+            "value": N / dt, "unit": "objects/s", "ms_per_step": dt * 1e3, "search_evals_per_s": Kt * N * M / dt, "kernel_ms_per_step": ms_knn,
+            "pdfs_normalised": bool(float((s - 1).abs().max().item()) < 1e-9),
+            "roofline": {"bound": "mfma", "kernel": "k_knn_mfma + k_knn_subset", "achieved": flops / (ms_knn * 1e-3) / 1e12, "peak": 157.3,
+                         "unit": "TFLOP/s (fp32 matrix, exhaustive-scan equivalent)", "frac": flops / (ms_knn * 1e-3) / 1e12 / 157.3,
+                         "note": "the exact k-d-ordered search multiplies only the tiles its boxes cannot exclude (~7 % of them, "
+                                 "profiles/README.md): a fraction above the tiles' share means the pipe did useful work faster than an exhaustive scan could"}}
+
+
+def sub_host_path(local, pd):
+    """the drop-in call as the reference's users make it: NumPy in, NumPy out, BruteForce.fit_predict(save_fits=False) at BASELINE
+    configs[2] (PCIe inclusive: 120 MB of objects in, 5.6 GB of PDFs out through page-locked blocks)"""
+    from frankenz_amd import BruteForce
+    N, M = 1000000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = make_problem(N, M, 20260101, 5, 1.0)
+    bf = BruteForce(Y, Ye, Ym, device=local)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        p = bf.fit_predict(X, Xe, Xm, z, ze, label_dict=pd, save_fits=False, verbose=False)
+        ts.append(time.perf_counter() - t0)
+        ok = bool(abs(float(p[:1024].sum(axis=1).max()) - 1) < 1e-9)
+        del p
+    return {"workload": "BruteForce.fit_predict(save_fits=False), NumPy -> NumPy, %d x %d x 5" % (N, M), "first_call_s": ts[0],
+            "steady_call_s": min(ts[1:]), "value": N * M / min(ts[1:]), "unit": "evals/s (PCIe inclusive)", "pdfs_normalised": ok,
+            "note": "the first call page-locks the 5.6 GB result block; later calls reuse it from the library's pool"}
 
 
 def main():
@@ -423,27 +558,7 @@ def main():
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                            "bytes_per_eval": 8, "note": "algorithmic: the plane read once"}}))
         else:
-            # what the search kernel did per wave (16 queries x one feature set): counters of THIS build at THIS shape, kept by
-            # tools/pmc_knn.sh in profiles/ (separate PMC passes; nothing is counted inside the timed region)
-            sprof = None
-            try:
-                cnt = {}
-                for ln in open(os.path.join(ROOT, "profiles", "r4_v2_pmc_knn.txt")):
-                    f = ln.split()
-                    if ln.startswith("k_knn_mfma") and "per_launch=" in ln:
-                        cnt[[w for w in f if w.startswith("SQ_")][0]] = float(ln.split("per_launch=")[1].split()[0])
-                wv = cnt["SQ_WAVES"]
-                import csv
-                kns = [float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_v2_kernel_stats_knn.csv")))
-                       if "k_knn_mfma" in r["Name"]][0]
-                simd_cycles = kns * 1e-9 * 2.4e9 * 256 * 4            # 256 CUs x 4 SIMDs at 2.4 GHz over the kernel's duration
-                sprof = {"source": "profiles/r4_v2_pmc_knn.txt + r4_v2_kernel_stats_knn.csv (1e5 objects x 25 sets x 1e5 models, k = 20)",
-                         "tiles_multiplied_per_wave": cnt["SQ_INSTS_MFMA"] / wv / 8.0, "tiles_per_set": (100000 + 63) // 64,
-                         "valu_insts_per_wave": cnt["SQ_INSTS_VALU"] / wv, "salu_insts_per_wave": cnt["SQ_INSTS_SALU"] / wv,
-                         "mfma_busy_frac": cnt["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,            # (counted in cycles)
-                         "valu_busy_frac": cnt["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles}           # (counted in units of 4 cycles)
-            except Exception:
-                pass
+            sprof = None      # (counter profiles of the search live in profiles/, stamped with the build they were taken on: not repeated here)
             print(json.dumps({"metric": "KMCkNN objects/sec (K=25 exact top-20 searches + subset PDFs)",
                               "value": N_total * args.steps / dt, "unit": "objects/s",
                               "search_evals_per_s": 25.0 * N_total * M * args.steps / dt, "n_gpus": world,
@@ -477,7 +592,11 @@ def main():
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
             try:
+                from frankenz_amd._lib import source_id
+                sid = source_id()
                 for ent in json.load(open(prof)).get("entries", []):
+                    if ent.get("source_id") != sid:           # counters of another build: not reported
+                        continue
                     if ent.get("form") == form and ent.get("mode") == args.mode and ent.get("model_err") == args.model_err \
                             and ent.get("n_band", 5) == args.nband and abs(ent.get("evals_per_launch", 0) - evals_per_launch) <= 0.01 * evals_per_launch:
                         traffic = ent["hbm_bytes_per_launch"]; traffic_src = ent.get("source")
@@ -528,7 +647,7 @@ def main():
                          "kernel": form, "achieved": ach,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VALU_PEAK_TFLOPS if ach else None, "traffic": traffic,
-                         "traffic_source": traffic_src or "no PMC entry for this kernel form and launch shape in profiles/pmc_latest.json",
+                         "traffic_source": traffic_src or "no PMC entry of THIS build (source stamp) for this kernel form and launch shape in profiles/pmc_latest.json",
                          "flops_per_eval": flops_eval,
                          "avg_launch_ms": ms_launch, "evals_per_launch": evals_per_launch,
                          "modec_iterations_per_step": (tm["n_modec"] / args.steps - 2) if fam == "modec" else None},   # minus the two timed scopes (iteration driver, final pass)
@@ -570,6 +689,15 @@ def main():
                                                    torch.from_numpy(Xm_c).to(dev)),
                                              note="mode A, per-model errors, 2 % of object bands and 2 % of model bands missing "
                                                   "(--model-err varying --mask-frac 0.02 --model-mask-frac 0.02)")
+        if "roofline_general" in out:
+            # every BASELINE config the line's own workload does not cover, as sub-records (2-3 steps each; a failure is recorded, not raised)
+            pp = _sub(lambda: sub_planes_predict(eng, dev, torch, pd))
+            out["planes"] = pp.get("planes", pp); out["predict"] = pp.get("predict", pp)
+            out["modeC"] = _sub(lambda: sub_modec(eng, dev, torch, pd))
+            out["knn"] = _sub(lambda: sub_knn(dev, torch, pd, local))
+            del dX, dXe, dXm, d_pdf
+            torch.cuda.empty_cache()
+            out["host_path"] = _sub(lambda: sub_host_path(local, pd))
         if cpu1 is not None:
             out["cpu_baseline"] = cpu1
             out["speedup_vs_cpu_core"] = value / cpu1["value"]

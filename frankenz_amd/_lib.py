@@ -10,6 +10,19 @@ LIB_PATH = os.environ.get("FRANKENZ_HIP_LIB",
                           os.path.join(_HERE, "csrc", "libfrankenz_hip.so"))
 
 
+def source_id():
+    """short hash of the kernel sources the shipped library is built from (csrc/*.hip, *.h, *.inc and the ABI header): the stamp
+    under which profiles/pmc_latest.json keeps counter values, so that bench.py reports them only for the build they were taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc")))
+    for f in files + [os.path.join("..", "..", "include", "frankenz_hip.h")]:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class LikeOpts(C.Structure):
     _fields_ = [("free_scale", C.c_int32), ("ignore_model_err", C.c_int32),
                 ("dim_prior", C.c_int32), ("max_iter", C.c_int32),

@@ -41,5 +41,7 @@ out = {}
 for k, c in tot.items():
     if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
         out[k] = {'fetch_KB': c['FETCH_SIZE'], 'write_KB': c['WRITE_SIZE'], 'hbm_bytes_per_launch': (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0}
-json.dump({'bench_args': args, 'kernels': out}, open('gpurun_out/pmc_%s.json' % tag, 'w'), indent=1)
+sys.path.insert(0, '.')
+from frankenz_amd._lib import source_id
+json.dump({'bench_args': args, 'source_id': source_id(), 'kernels': out}, open('gpurun_out/pmc_%s.json' % tag, 'w'), indent=1)
 PY
