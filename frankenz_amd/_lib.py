@@ -90,6 +90,10 @@ ABI = {
     "fz_pdfs_resample": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _F64, _F64, _I32, _P]),
     "fz_overlap_nz": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _F64, _P, _P]),
     "fz_nz_assign": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "fz_net_select": (C.c_int, [_P, _P, _I64, _I32, _I32, _F64, _F64, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "fz_net_table": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _P]),
+    "fz_net_gather": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, C.c_uint64, _P]),
+    "fz_net_stack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I64, _P, _P, _P]),
     "fz_knn_search_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _F64, _F64, C.POINTER(LikeOpts),
                                                   C.POINTER(KdeOpts), C.POINTER(Prior)] + [_P] * 12),
     "fz_knn_fit_predict_prior": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, C.POINTER(LikeOpts),

@@ -10,6 +10,7 @@
 #include "fz_launch.h"
 #include "fz_modec.h"
 #include "fz_summary.h"
+#include "fz_net.h"
 
 using namespace fz;
 
@@ -1127,6 +1128,7 @@ extern "C" int fz_predict_logwt(fz_ctx* c, const double* logwt, int64_t N, int32
 
 #include "fz_knn_host.inc"
 #include "fz_summary_host.inc"
+#include "fz_net_host.inc"
 
 #ifdef FZ_KM_STATS
 extern "C" int fz_debug_kmstats(unsigned long long* out, int reset) {

@@ -105,6 +105,7 @@ struct fz_ctx {
     DevBuf d_pl[7];            // staging planes
     DevBuf d_mc[4], d_mcerr, d_mcfn, d_mcact, d_mccnt, d_mcniter; int64_t mc_niter_n = 0;
     DevBuf d_cand, d_kv;
+    DevBuf d_net[10];                // staging of host arrays handed to the fz_net_* entry points
     DevBuf d_sgrid, d_sloss;         // pdfs_summarize: grid / loss matrix   // candidate lists / KDE table view / per-object statistics of the single-pass kernels
     // additive ln-prior of the chunk being processed (tab == nullptr: none); set by bind_prior
     fz::PriorView prior{};
@@ -124,6 +125,7 @@ struct fz_ctx {
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_omap, &d_redo, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_kgbox, &d_ktbox, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kqperm, &d_kqcnt};
         for (auto& b : d_pl) v.push_back(&b);
+        for (auto& b : d_net) v.push_back(&b);
         for (auto& b : d_mc) v.push_back(&b);
         return v;
     }

@@ -317,6 +317,28 @@ class Engine(object):
         check(self.lib.fz_knn_predict_logwt(self.h, ptr(logwt), ptr(neighbors), ptr(nnbr), n, int(W),
                                             C.byref(kopts), ptr(pdfs), ptr(lmap), ptr(levid)))
 
+    # -- inference through a trained network (networks.py; fz_net.h) -----------
+    def net_select(self, lnprob, use_wt, wt_thresh, cdf_thresh, match, csr_off, nsel, sel, rawlen=None, lmap=None, levid=None):
+        n, nn = lnprob.shape
+        nnodes = 0 if csr_off is None else len(csr_off) - 1
+        check(self.lib.fz_net_select(self.h, ptr(lnprob), n, nn, int(bool(use_wt)), float(wt_thresh), float(cdf_thresh), ptr(match),
+                                     ptr(csr_off), nnodes, ptr(nsel), ptr(sel), ptr(rawlen), ptr(lmap), ptr(levid)))
+
+    def net_table(self, nsel, sel, match, csr_off, csr_items, W, idx):
+        n, nn = sel.shape
+        check(self.lib.fz_net_table(self.h, ptr(nsel), ptr(sel), n, nn, ptr(match), ptr(csr_off), ptr(csr_items), len(csr_off) - 1,
+                                    int(W), ptr(idx)))
+
+    def net_gather(self, plane, nsel, sel, W, pad, out):
+        n, nn = sel.shape
+        bits = int(np.array([pad], dtype=plane.dtype).view(np.uint64)[0])
+        check(self.lib.fz_net_gather(self.h, ptr(plane), ptr(nsel), ptr(sel), n, nn, int(W), bits, ptr(out)))
+
+    def net_stack(self, lnprob, nsel, sel, match, node_pdfs, pdfs, lmap=None, levid=None):
+        n, nn = sel.shape
+        check(self.lib.fz_net_stack(self.h, ptr(lnprob), ptr(nsel), ptr(sel), n, nn, ptr(match), ptr(node_pdfs), node_pdfs.shape[0],
+                                    node_pdfs.shape[1], ptr(pdfs), ptr(lmap), ptr(levid)))
+
     def pdfs_summarize(self, pdfs, pgrid, renormalize, urand, loss, widths, wscale, stats, n=None):
         n = len(pdfs) if n is None else n
         check(self.lib.fz_pdfs_summarize(self.h, ptr(pdfs), n, len(pgrid), ptr(pgrid), int(bool(renormalize)),

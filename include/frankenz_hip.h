@@ -265,6 +265,35 @@ int  fz_overlap_nz(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const 
 int  fz_nz_assign(fz_ctx* ctx, const double* pdfs, int64_t N, int64_t G, const double* nz, const double* u,
                   int64_t* bins, int64_t* counts);
 
+/* ---- inference through a trained network (networks.py:244-356, 782-936, 1200-1473) ----
+ * The network is DATA here (node positions in data space and, after populate_network, the per-node model lists); training it
+ * is out of scope.  Node ln-probabilities come from fz_fit with the (matched) nodes uploaded as noiseless, unmasked models
+ * (networks.py:305-307, 874-876).  Every array may live in host or device memory.
+ *
+ * fz_net_select -- which nodes an object's (N, Nn) ln-probabilities select, in the reference's order (networks.py:885-896, 316-327):
+ *   use_wt != 0: lnprob > ln(wt_thresh) + max(lnprob), strict, node index ascending (wt_thresh <= 0 or -inf: every node);
+ *   use_wt == 0: ascending ln-prob, the prefix whose running probability exp(l - logsumexp) stays <= 1 - cdf_thresh.
+ *   match (Nn, or NULL = identity): the node behind column c (networks.py:873 match_sel); csr_off (Nnodes + 1, or NULL): offsets of
+ *   the per-node lists.  Out: nsel (N) int32, sel (N, Nn) int32 column indices (first nsel[i] valid), rawlen (N) int64 summed
+ *   list length of the selected nodes (NULL if not wanted), lmap / levid (N): max and logsumexp over the selected entries
+ *   (networks.py:330-333; NULL if not wanted).  Nn <= 4096. */
+int  fz_net_select(fz_ctx* ctx, const double* lnprob, int64_t N, int32_t Nn, int32_t use_wt, double wt_thresh,
+                   double cdf_thresh, const int32_t* match, const int64_t* csr_off, int64_t Nnodes, int32_t* nsel,
+                   int32_t* sel, int64_t* rawlen, double* lmap, double* levid);
+/* networks.py:912-918: idx (N, W) = the lists (csr_items, int64 model indices) of every object's selected nodes concatenated in
+ * order, padded to W with the row's first entry -- the table fz_knn_fit_predict takes: it removes repeats in first-appearance
+ * order, which is pandas.unique (networks.py:919), and fits the remaining models (networks.py:925-928). */
+int  fz_net_table(fz_ctx* ctx, const int32_t* nsel, const int32_t* sel, int64_t N, int32_t Nn, const int32_t* match,
+                  const int64_t* csr_off, const int64_t* csr_items, int64_t Nnodes, int64_t W, int64_t* idx);
+/* networks.py:907-909 (nodes_only): out (N, W) 8-byte elements = plane (N, Nn) at the selected columns, `pad_bits` beyond nsel. */
+int  fz_net_gather(fz_ctx* ctx, const void* plane, const int32_t* nsel, const int32_t* sel, int64_t N, int32_t Nn, int32_t W,
+                   uint64_t pad_bits, void* out);
+/* networks.py:1459-1466, 1473 (nodes_only): pdfs (N, G) = softmax over the selected ln-probabilities @ node_pdfs (Nnodes, G) rows of
+ * the selected nodes, each row divided by its sum; lmap / levid (N) over the selected entries. */
+int  fz_net_stack(fz_ctx* ctx, const double* lnprob, const int32_t* nsel, const int32_t* sel, int64_t N, int32_t Nn,
+                  const int32_t* match, const double* node_pdfs, int64_t Nnodes, int64_t G, double* pdfs, double* lmap,
+                  double* levid);
+
 /* diagnostic: evaluate one of the library's device math helpers elementwise
  * (which: 0 v_rcp_f64 seed, 1 / 2 rcp with one / two Newton steps, 3 log_pos,
  * 4 exp_neg).  Used by tests to pin their accuracy against NumPy. */

@@ -642,6 +642,67 @@ def g13():
     save('g13_nz_assign_law', pdfs=pd[pick], nz=nz, pvals=pv[::reps], counts=counts, reps=np.array(reps))
 
 
+def g14():
+    """_Network inference (networks.py:782-936, 938-1128, 1130-1473) with hand-set nodes: populate_network, then fit / predict /
+    fit_predict through the network for nodes_only x discrete x both thresholding rules, and the per-node PDFs (get_pdfs)."""
+    from frankenz.networks import _Network
+    Y, Ye, Ym, X, Xe, Xm, z, ze = small_problem(1414, 14, 120)
+    rs = np.random.RandomState(14)
+    nodes = Y[rs.choice(len(Y), 15, replace=False)] * rs.lognormal(0, 0.15, size=(15, 5))
+    nodes[13] = 1e4                                              # a node nothing maps to (Nmatch = 0: dropped by match_sel)
+    pdict = rpdf.PDFDict(np.arange(0, 7 + 1e-5, .01), np.linspace(.005, 2, 500))
+    out = dict(models=Y, models_err=Ye, models_mask=Ym, nodes=nodes, data=X, data_err=Xe, data_mask=Xm, labels=z, label_errs=ze)
+    net = _Network(Y.copy(), Ye.copy(), Ym.copy())
+    net.nodes = nodes.copy(); net.NNODE = len(nodes)
+    net.populate_network(verbose=False)
+    out['Nmatch'] = net.nodes_Nmatch
+    cat = lambda lst, dt: np.concatenate([np.asarray(v, dtype=dt) for v in lst]) if len(lst) else np.zeros(0, dtype=dt)
+    for disc in (False, True):
+        npdf, (nlm, nle) = net.get_pdfs(z, ze, label_dict=pdict, return_gof=True, discrete=disc, verbose=False)
+        out['nodepdfs_d%d' % disc], out['nodelmap_d%d' % disc], out['nodelevid_d%d' % disc] = npdf, nlm, nle
+    rules = {'wt': dict(wt_thresh=1e-3), 'cdf': dict(wt_thresh=None, cdf_thresh=0.05)}
+    for rname, rule in rules.items():
+        for nodes_only in (False, True):
+            for disc in (False, True):
+                tag = '%s_n%d_d%d' % (rname, nodes_only, disc)
+                pdfs, (lm, le) = net.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=pdict, nodes_only=nodes_only,
+                                                 discrete=disc, return_gof=True, verbose=False, save_fits=True,
+                                                 track_scale=nodes_only, **rule)
+                out[tag + '_pdfs'], out[tag + '_lmap'], out[tag + '_levid'] = pdfs, lm, le
+                out[tag + '_Nneighbors'] = net.Nneighbors
+                out[tag + '_neighbors'] = cat(net.neighbors, 'int')
+                out[tag + '_lnprob'] = cat(net.fit_lnprob, 'float')
+                out[tag + '_lnlike'] = cat(net.fit_lnlike, 'float')
+                out[tag + '_chi2'] = cat(net.fit_chi2, 'float')
+                out[tag + '_Ndim'] = cat(net.fit_Ndim, 'int')
+                if nodes_only:
+                    out[tag + '_scale'] = cat(net.fit_scale, 'float')
+                # predict() from the stored fits (and fit() alone must store the same)
+                p2, (lm2, le2) = net.predict(z, ze, label_dict=pdict, return_gof=True, discrete=disc, verbose=False)
+                out[tag + '_pdfs_predict'] = p2
+                net.fit(X.copy(), Xe.copy(), Xm.copy(), nodes_only=nodes_only, discrete=disc, verbose=False, track_scale=nodes_only, **rule)
+                assert np.array_equal(cat(net.neighbors, 'int'), out[tag + '_neighbors'])
+    # a network mapped with a FIXED-scale node likelihood: node 13 (fluxes of 1e4) then matches no model (Nmatch = 0) and is dropped
+    # from the node fits (match_sel, networks.py:873)
+    net2 = _Network(Y.copy(), Ye.copy(), Ym.copy())
+    net2.nodes = nodes.copy(); net2.NNODE = len(nodes)
+    net2.populate_network(verbose=False, track_scale=False, lpnet_kwargs={'free_scale': False, 'ignore_model_err': True})
+    out['fx_Nmatch'] = net2.nodes_Nmatch
+    assert net2.nodes_Nmatch[13] == 0
+    for nodes_only in (False, True):
+        tag = 'fx_n%d' % nodes_only
+        pdfs, (lm, le) = net2.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=pdict, nodes_only=nodes_only, return_gof=True,
+                                          verbose=False, save_fits=True)
+        out[tag + '_pdfs'], out[tag + '_lmap'], out[tag + '_levid'] = pdfs, lm, le
+        out[tag + '_Nneighbors'] = net2.Nneighbors
+        out[tag + '_neighbors'] = cat(net2.neighbors, 'int')
+        out[tag + '_lnprob'] = cat(net2.fit_lnprob, 'float')
+    # the direct KDE on a grid, one combination
+    pg, (lmg, leg) = net.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_grid=pdict.grid, return_gof=True, verbose=False)
+    out['grid_pdfs'], out['grid_lmap'], out['grid_levid'] = pg, lmg, leg
+    save('g14_network_inference', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for nm in sys.argv[1:]:
@@ -650,6 +711,6 @@ if __name__ == '__main__':
     save('g0_meta', numpy=np.array(np.__version__),
          scipy=np.array(scipy.__version__), pandas=np.array(pandas.__version__),
          reference=np.array('joshspeagle/frankenz v0.3.5 @ /root/reference'))
-    which = sys.argv[1:] or (['g%d' % k for k in range(1, 14)] + ['g2b'])
+    which = sys.argv[1:] or (['g%d' % k for k in range(1, 15)] + ['g2b'])
     for name in which:
         globals()[name]()

@@ -399,3 +399,67 @@ def test_knn_limits_are_refused_loudly_where_the_reference_would_run():
             nn.fit(X, 0.1 * np.ones_like(X), np.ones_like(X), k=k, verbose=False)
         with pytest.raises(NotImplementedError, match='k <= 256 and K\\*k <= 4096'):
             nn.fit_predict(X, 0.1 * np.ones_like(X), np.ones_like(X), np.zeros(300), np.ones(300), label_grid=np.arange(5.), k=k, verbose=False)
+
+
+G14_CASES = [(r, n, d) for r in ('wt', 'cdf') for n in (0, 1) for d in (0, 1)]
+
+
+def _g14_net(g, fixed=False):
+    kw = dict(track_scale=False, free_scale=False, ignore_model_err=True) if fixed else {}
+    return fo.populate_network(g['nodes'], g['models'].copy(), g['models_err'].copy(), g['models_mask'].copy(), **kw)
+
+
+@pytest.mark.parametrize('rule,nodes_only,disc', G14_CASES)
+def test_g14_network_inference(rule, nodes_only, disc):
+    """_Network.fit / fit_predict / predict through a populated network (networks.py:782-936, 1130-1473): neighbour lists in the
+    reference's order, the fitted ln-probabilities and the PDFs, for both thresholding rules x nodes_only x discrete."""
+    g = load_golden('g14_network_inference')
+    d = demo_dict()
+    net = _g14_net(g)
+    np.testing.assert_array_equal(net['Nmatch'], g['Nmatch'])
+    rk = dict(wt_thresh=1e-3) if rule == 'wt' else dict(wt_thresh=None, cdf_thresh=0.05)
+    tag = '%s_n%d_d%d' % (rule, nodes_only, disc)
+    p, lm, le, lists = fo.network_fit_predict(net, g['nodes'], g['data'].copy(), g['data_err'].copy(), g['data_mask'].copy(), g['models'],
+                                              g['models_err'], g['models_mask'], g['labels'], g['label_errs'], label_dict=d,
+                                              nodes_only=bool(nodes_only), discrete=bool(disc), **rk)
+    np.testing.assert_array_equal(np.array([len(v) for v in lists['neighbors']]), g[tag + '_Nneighbors'])
+    np.testing.assert_array_equal(np.concatenate(lists['neighbors']), g[tag + '_neighbors'])
+    eq(np.concatenate(lists['lnprob']), g[tag + '_lnprob']); eq(np.concatenate(lists['chi2']), g[tag + '_chi2'])
+    np.testing.assert_array_equal(np.concatenate(lists['Ndim']), g[tag + '_Ndim'])
+    if nodes_only:
+        eq(np.concatenate(lists['scale']), g[tag + '_scale'])
+    eq(lm, g[tag + '_lmap']); eq(le, g[tag + '_levid'])
+    eq(p, g[tag + '_pdfs'], rtol=1e-10, atol=1e-15)
+    eq(g[tag + '_pdfs_predict'], g[tag + '_pdfs'], rtol=1e-12, atol=1e-15)      # (the reference's predict() from its stored fits: the same rows)
+
+
+@pytest.mark.parametrize('disc', [0, 1])
+def test_g14_node_pdfs(disc):
+    """_Network.get_pdfs (networks.py:413-560)"""
+    g = load_golden('g14_network_inference')
+    p, lm, le = fo.network_node_pdfs(_g14_net(g), g['labels'], g['label_errs'], label_dict=demo_dict(), discrete=bool(disc))
+    eq(p, g['nodepdfs_d%d' % disc], rtol=1e-10, atol=1e-15); eq(lm, g['nodelmap_d%d' % disc]); eq(le, g['nodelevid_d%d' % disc])
+
+
+@pytest.mark.parametrize('nodes_only', [0, 1])
+def test_g14_nodes_without_models_are_left_out(nodes_only):
+    """a network mapped with the fixed-scale node likelihood: node 13 matches no model and is dropped from the node fits (networks.py:873)"""
+    g = load_golden('g14_network_inference')
+    net = _g14_net(g, fixed=True)
+    np.testing.assert_array_equal(net['Nmatch'], g['fx_Nmatch'])
+    assert net['Nmatch'][13] == 0
+    tag = 'fx_n%d' % nodes_only
+    p, lm, le, lists = fo.network_fit_predict(net, g['nodes'], g['data'].copy(), g['data_err'].copy(), g['data_mask'].copy(), g['models'],
+                                              g['models_err'], g['models_mask'], g['labels'], g['label_errs'], label_dict=demo_dict(),
+                                              nodes_only=bool(nodes_only), lpnet_kwargs={'free_scale': False, 'ignore_model_err': True})
+    np.testing.assert_array_equal(np.concatenate(lists['neighbors']), g[tag + '_neighbors'])
+    eq(np.concatenate(lists['lnprob']), g[tag + '_lnprob']); eq(lm, g[tag + '_lmap']); eq(le, g[tag + '_levid'])
+    eq(p, g[tag + '_pdfs'], rtol=1e-10, atol=1e-15)
+
+
+def test_g14_grid_kde():
+    g = load_golden('g14_network_inference')
+    d = demo_dict()
+    p, lm, le, _ = fo.network_fit_predict(_g14_net(g), g['nodes'], g['data'].copy(), g['data_err'].copy(), g['data_mask'].copy(), g['models'],
+                                          g['models_err'], g['models_mask'], g['labels'], g['label_errs'], label_grid=d.grid)
+    eq(p, g['grid_pdfs'], rtol=1e-10, atol=1e-15); eq(lm, g['grid_lmap']); eq(le, g['grid_levid'])
