@@ -83,6 +83,15 @@ def _lists_from_plane(lnprob, scale, scale_err, wt_thresh, cdf_thresh, track_sca
     out.models_bmu = np.argmax(lnprob, axis=1)                       # best-matching unit per model
     eng = eng if eng is not None else get_engine(None)
     nsel, sel, _, lmap, levid = _select(eng, np.ascontiguousarray(lnprob), wt_thresh, cdf_thresh, want_stats=True)
+    return _lists_from_selection(lnprob, scale, scale_err, nsel, sel, lmap, levid, track_scale)
+
+
+def _lists_from_selection(lnprob, scale, scale_err, nsel, sel, lmap, levid, track_scale):
+    """the transpose: per-model selections (nsel, sel: fz_net_select) -> per-node lists, as networks.py:335-352 appends them"""
+    Nmodels, Nnodes = lnprob.shape
+    out = NetworkMap()
+    rows = np.arange(Nmodels)
+    out.models_bmu = np.argmax(lnprob, axis=1)
     keep = np.arange(Nnodes)[None, :] < nsel[:, None]
     pair_model = np.nonzero(keep)[0]
     pair_node = sel[keep].astype(np.int64)

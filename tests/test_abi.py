@@ -115,17 +115,26 @@ def test_product_pdfdict_against_golden_g3():
 
 
 def test_network_lists_from_a_plane():
-    """host half of networks.populate_network (no GPU): the whole-plane segmented reductions against the
+    """host half of networks.populate_network (no GPU): the transpose of the per-model selections into per-node lists against the
     per-model walk of networks.py:310-354, for the weight threshold, the CDF rule and no threshold."""
     import numpy as np
     from scipy.special import logsumexp
-    from frankenz_amd.networks import _lists_from_plane
+    from frankenz_amd.networks import _lists_from_selection
     rs = np.random.RandomState(4)
     Nm, Nn = 57, 23
     lnp = -0.5 * rs.chisquare(3, size=(Nm, Nn)) * rs.choice([1., 8.], size=(Nm, 1))
     sc, se = rs.uniform(0.5, 2, (Nm, Nn)), rs.uniform(0.01, 0.1, (Nm, Nn))
     for wt, cdf, ts in ((1e-3, 2e-4, True), (None, 2e-2, True), (1e-12, 2e-4, False), (0.3, 2e-4, True)):
-        r = _lists_from_plane(lnp, sc, se, wt, cdf, ts)
+        # (the selection itself is the device's, fz_net_select -- tests/test_hip_network.py; here it is written down with NumPy)
+        nsel = np.zeros(Nm, dtype=np.int32); selm = np.zeros((Nm, Nn), dtype=np.int32); lm = np.zeros(Nm); lv_ = np.zeros(Nm)
+        for i in range(Nm):
+            row = lnp[i]
+            if wt is not None:
+                sl = np.arange(Nn)[row > np.log(wt) + row.max()]
+            else:
+                o = np.argsort(row); c = np.cumsum(np.exp(row - logsumexp(row))[o]); sl = o[c <= 1. - cdf]
+            nsel[i] = len(sl); selm[i, :len(sl)] = sl; lm[i] = row[sl].max(); lv_[i] = logsumexp(row[sl])
+        r = _lists_from_selection(lnp, sc, se, nsel, selm, lm, lv_, ts)
         idxs = [[] for _ in range(Nn)]; lw = [[] for _ in range(Nn)]; ss = [[] for _ in range(Nn)]; bm = [[] for _ in range(Nn)]
         for i in range(Nm):
             row = lnp[i]
