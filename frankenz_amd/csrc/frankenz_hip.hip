@@ -703,7 +703,7 @@ static int run_cdf(fz_ctx* c, int64_t n, int L, int64_t M, const double* rows, c
     if (rc) return rc;
     FZCHK(c->d_kv.ensure(sizeof(KdeView)));
     FZCHK(copy_in(c, c->d_kv.p, &kv, sizeof(KdeView)));
-    const size_t per_wave = (size_t)kv.acc_stride * 8;
+    const size_t per_wave = (size_t)std::max(kv.acc_stride, 512) * 8;      // (the selection's 2 x 256-bucket histogram shares the row)
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
     const size_t lds = per_wave * wpb;

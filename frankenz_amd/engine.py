@@ -3,6 +3,7 @@ Thin object wrapper over one ``fz_ctx`` (one per GPU).  Everything numeric happe
 inside libfrankenz_hip.so; this file only marshals arrays.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -103,7 +104,9 @@ class _PinnedBlock(object):
     as its base; when the last view dies the block goes back to a small pool (page-locking 5.6 GB costs about as much
     as copying it) or to the runtime."""
     _pool = []                      # free blocks [(nbytes, ptr)], at most _POOL_MAX bytes in total
-    _POOL_MAX = 12 << 30
+    # One result block of the largest call so far stays page-locked between calls (page-locking 5.6 GB costs about as much as
+    # copying it); FRANKENZ_PINNED_POOL_GB sizes the pool (0: nothing is kept), ``release_pinned_pool()`` empties it.
+    _POOL_MAX = int(float(os.environ.get("FRANKENZ_PINNED_POOL_GB", "6")) * (1 << 30))
 
     def __init__(self, ptr_, nbytes, shape, dtype):
         self.ptr, self.nbytes = ptr_, nbytes
@@ -118,6 +121,13 @@ class _PinnedBlock(object):
                 _lib.load().fz_host_free(self.ptr)
         except Exception:           # interpreter shutdown
             pass
+
+
+def release_pinned_pool():
+    """give every pooled page-locked block back to the runtime (hosts short of unswappable memory, several ranks per node)"""
+    pool = _PinnedBlock._pool
+    while pool:
+        _lib.load().fz_host_free(pool.pop()[1])
 
 
 def pinned_empty(shape, dtype=np.float64, min_bytes=1 << 24):
@@ -377,6 +387,12 @@ class Engine(object):
         engine); 1: wait for ``stream`` only (an int ``hipStream_t``, e.g. ``torch.cuda.current_stream().cuda_stream``;
         None / 0: the legacy default stream); 2: inputs are complete, no wait."""
         check(self.lib.fz_set_producer_stream(self.h, int(stream or 0), int(mode)))
+        self._producer = (stream, int(mode))
+
+    def producer_stream(self):
+        """(stream, mode) of the last ``set_producer_stream`` (a fresh context: (None, 0)): what a caller that changes the contract
+        for the length of one call puts back"""
+        return getattr(self, "_producer", (None, 0))
 
     def modec_info(self):
         """mode C since the last ``timing_reset``: ``(ambiguous objects re-run with IEEE divisions, iterations of the

@@ -27,13 +27,24 @@ _GEN_CHUNK = 4096
 
 
 class _FeatureSet(object):
-    """Stand-in for one ``scipy.spatial.KDTree`` of the reference's ``KDTrees`` list:
-    holds the float32 Monte-Carlo feature set (``data``, as the tree would)."""
+    """One entry of the reference's ``KDTrees`` list (knn.py:186): holds the float32 Monte-Carlo feature set (``data``, as the tree
+    would).  The library's own searches run over all K sets on the device and never build a tree; a caller that pokes at
+    ``KDTrees[i]`` directly -- ``.query(...)``, ``.query_ball_point(...)`` -- gets the SciPy tree the reference would have handed
+    out, built on first use."""
 
     def __init__(self, data, leafsize):
         self.data = data
         self.n, self.m = data.shape
         self.leafsize = leafsize
+        self._tree = None
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        if self._tree is None:
+            from scipy.spatial import KDTree
+            self._tree = KDTree(self.data, leafsize=self.leafsize)      # knn.py:186
+        return getattr(self._tree, name)
 
 
 class _PreparedKnn(object):
@@ -68,6 +79,10 @@ class _PreparedKnn(object):
         q = query_features
         if not hasattr(q, "data_ptr"):
             q = np.ascontiguousarray(q, dtype=np.float64)
+        elif str(q.dtype) != 'torch.float64' or not q.is_contiguous() or (on_dev and q.device != data.device) or \
+                (q.is_cuda and q.device.index != eng.device):
+            # (a tensor goes to the library as a raw pointer: anything else would be read as float64 (N, F) garbage)
+            raise ValueError("a tensor `query_features` must be a contiguous float64 tensor on the engine's device")
         if tuple(q.shape) != (Ndata, nn.NDIM):
             raise ValueError("`query_features` must have shape (Ndata, Nfilt) = (%d, %d)" % (Ndata, nn.NDIM))
         if out is None:

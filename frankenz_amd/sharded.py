@@ -156,8 +156,10 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
     dX, dXe, dXm = dv(data), dv(data_err), dv(data_mask)
     eng = fitter._engine()
     lib_stream = on_gpu and hasattr(eng, "set_producer_stream")
+    prev_contract = eng.producer_stream() if hasattr(eng, "producer_stream") else (None, 0)
     if lib_stream:
         eng.set_producer_stream(torch.cuda.current_stream().cuda_stream, 1)
+    works = []
     try:
         # the reference cleans every object in place (pdf.py:310-311); every rank holds the full object arrays, so every
         # rank's copy ends up cleaned, as after the single-process call (N x B values: negligible)
@@ -175,10 +177,14 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
         # models, dictionary, labels (feature sets): on the device once, not once per round -- and not at all when the caller
         # hands in the handle of an earlier ``prepare_fit_predict`` (a driver that calls this function step after step)
         prep = kwargs.get("prepared")
+        if prep is not None and is_knn and search:
+            want = (search.get("k", prep.search[0]), search.get("lp_norm", prep.search[1]), search.get("distance_upper_bound", prep.search[2]))
+            if tuple(want) != tuple(prep.search):
+                raise ValueError("search arguments %r disagree with the prepared handle's %r" % (want, prep.search))
         if prep is None:
             prep = fitter.prepare_fit_predict(model_labels, model_label_errs, label_dict=label_dict, label_grid=label_grid,
                                               kde_kwargs=kwargs.get("kde_kwargs"), lprob_kwargs=kwargs.get("lprob_kwargs"), **search)
-        works, t_comp = [], 0.0
+        t_comp = 0.0
         sync()
         t_start = time.perf_counter()
         for c in range(C):
@@ -209,8 +215,15 @@ def _overlapped(fitter, data, data_err, data_mask, model_labels, model_label_err
         sync()
         t_end = time.perf_counter()
     finally:
+        # collectives already queued are waited for whatever ended the loop (an exception in a later round must not leave them
+        # writing into tensors that are about to go away), and the caller's own stream contract is put back
+        for w in works:
+            try:
+                w.wait()
+            except Exception:       # noqa: BLE001
+                pass
         if lib_stream:
-            eng.set_producer_stream(None, 0)
+            eng.set_producer_stream(*prev_contract)
     t_total = t_end - t_start
     nbytes = rows * G * 8
     last_stats.clear()

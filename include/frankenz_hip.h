@@ -46,11 +46,14 @@ typedef struct fz_like_opts {
     int32_t max_iter;         /* guard for the unbounded loop at pdf.py:199;
                                  <=0 means 10000.  Hitting it is an error.   */
     double  ltol;             /* pdf.py:199  ltol              (default 1e-4) */
-    int32_t exact_evidence;   /* extension (no reference counterpart, default 0): 1 = every weight of the
-                                 fused path's ln-evidence is formed and summed in fp64 (the reference's
-                                 logsumexp, bruteforce.py:619, is fp64 throughout).  0 = the default bodies
-                                 sum the weights BELOW wt_thresh of the best in fp32 (~1e-9 relative on
-                                 levid; lmap, PDFs and every stacked weight are fp64 either way).        */
+    int32_t exact_evidence;   /* extension (no reference counterpart, default 0).  The default kernel of the fused
+                                 path (k_hist, every form) forms and sums EVERY weight in fp64 -- the reference's
+                                 logsumexp, bruteforce.py:619 -- and this flag changes nothing there.  It matters
+                                 only to the older k_fused weight-space body, which serves what k_hist does not
+                                 take (ln-prior tables, the direct grid KDE, many dictionary widths, wild values):
+                                 0 = that body sums the weights BELOW wt_thresh of the best in fp32 (~1e-9
+                                 relative on levid; lmap, PDFs and every stacked weight are fp64 either way),
+                                 1 = its all-fp64 ln-space body.                                          */
     int32_t reserved_;        /* keep 0 */
 } fz_like_opts;
 

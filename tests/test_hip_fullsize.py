@@ -9,6 +9,14 @@ import frankenz_oracle as fo
 from conftest import EVID
 
 pytestmark = pytest.mark.gpu
+EVID64 = dict(rtol=1e-12, atol=1e-12)      # every form of k_hist forms and sums its weights in fp64 (DESIGN: precision)
+
+
+def evid_tol():
+    """the ln-evidence tolerance of the route the LAST call took: 1e-12 on the one-pass kernel (fp64 throughout), the looser
+    EVID only where round 2's k_fused (fp32 remainder of the evidence) served the call"""
+    from frankenz_amd.engine import get_engine
+    return EVID64 if get_engine().last_form().startswith('k_hist') else EVID
 SDSS_SIGMA = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
 
 
@@ -30,11 +38,14 @@ def dicts():
     return PDFDict(grid, sg), fo.KernelDict(grid, sg)
 
 
-@pytest.mark.parametrize('kw,prob', [({}, {}), ({'free_scale': True, 'ignore_model_err': True}, {}),
-                                     ({}, {'varying_errors': True}), ({}, {'mask_frac': 0.02}),
-                                     ({'dim_prior': False}, {'varying_errors': True, 'mask_frac': 0.02})])
-def test_config2_fused_properties_and_sample_parity(kw, prob):
+@pytest.mark.parametrize('kw,prob,form', [({}, {}, 'k_hist<screen>'), ({'free_scale': True, 'ignore_model_err': True}, {}, 'k_hist<exact>'),
+                                          ({}, {'varying_errors': True}, 'k_hist<screen>'),
+                                          ({}, {'mask_frac': 0.02}, 'k_hist<screen> (per-object band counts)'),
+                                          ({}, {'varying_errors': True, 'mask_frac': 0.02}, 'k_hist<screen> (segmented models)'),
+                                          ({'dim_prior': False}, {'varying_errors': True, 'mask_frac': 0.02}, 'k_fused')])
+def test_config2_fused_properties_and_sample_parity(kw, prob, form):
     from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
     n, m = 100000, 100000
     Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, **prob)
     d, od = dicts()
@@ -42,6 +53,8 @@ def test_config2_fused_properties_and_sample_parity(kw, prob):
     Xc, Xec, Xmc = X.copy(), Xe.copy(), Xm.copy()
     p, (lm, le) = bf.fit_predict(Xc, Xec, Xmc, z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True,
                                  save_fits=False, verbose=False)
+    assert get_engine().last_form() == form                                      # (a silent fall-back to another kernel fails here)
+    tol = evid_tol()
     assert p.shape == (n, 701) and np.isfinite(p).all() and (p >= 0).all()
     np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=0, atol=1e-12)          # normalised
     assert np.all(le >= lm - 1e-12) and np.all(le <= lm + np.log(m) + 1e-9)    # max <= logsumexp <= max + ln M
@@ -50,14 +63,14 @@ def test_config2_fused_properties_and_sample_parity(kw, prob):
     sl = slice(31337, 31337 + 5000)
     p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d,
                                     lprob_kwargs=kw, return_gof=True, save_fits=False, verbose=False)
-    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **EVID)   # another launch geometry: the fp32 part of the evidence sums in another order
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **tol)    # (another launch geometry: the sums run in another order)
     np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)               # LDS float atomics: order may differ
     # oracle on a random sample of objects against the FULL model set
     pick = np.random.RandomState(1).choice(n, 100, replace=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze,
                                              label_dict=od, **kw)
     np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
-    np.testing.assert_allclose(le[pick], rle, **EVID)
+    np.testing.assert_allclose(le[pick], rle, **tol)
     np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
 
 
@@ -81,9 +94,12 @@ def test_config1_materialised_planes_and_predict_route():
     rows = pick[:4]
     want = [np.sum((X[i][None, :] - Y) ** 2 / (Xe[i][None, :] ** 2 + Ye ** 2)) for i in rows]
     np.testing.assert_allclose(bf.fit_chi2[rows].sum(axis=1), want, rtol=1e-11)
+    from frankenz_amd.engine import get_engine
     p_pred, (lm1, le1) = bf.predict(z, ze, label_dict=d, return_gof=True, verbose=False)
+    assert get_engine().last_form() == 'k_plane_rows'
     p_fused, (lm2, le2) = BruteForce(Y, Ye, Ym).fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d,
                                                             return_gof=True, save_fits=False, verbose=False)
+    assert get_engine().last_form() == 'k_hist<screen>'
     # fused: ln L(mode) + ln of the best weight, from a chi2 formed as sum (xs - y s)^2 (fz_hist.h, C2OP: one rounding of x s,
     # 1.1e-16 S/N on each difference) -- the stored row's maximum comes from the exact-difference form: 1e-13 apart at most here
     # (observed 8e-15; until the middle of round 4 both used the exact difference and agreed to two ulps)
@@ -118,7 +134,9 @@ def test_config3_full_size_one_million_objects():
     Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
     d, od = dicts()
     bf = BruteForce(Y, Ye, Ym)
+    from frankenz_amd.engine import get_engine
     p, (lm, le) = bf.fit_predict(X, Xe, Xm, z, ze, label_dict=d, return_gof=True, save_fits=False, verbose=False)
+    assert get_engine().last_form() == 'k_hist<screen>'                          # the bench's kernel, fp64 throughout
     assert p.shape == (n, 701)
     s = p.sum(axis=1)
     assert np.isfinite(s).all() and np.abs(s - 1.0).max() < 1e-12 and p.min() >= 0.0
@@ -126,11 +144,11 @@ def test_config3_full_size_one_million_objects():
     sl = slice(777777, 777777 + 3000)
     p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d, return_gof=True,
                                     save_fits=False, verbose=False)
-    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **EVID)   # another launch geometry: the fp32 part of the evidence sums in another order
+    np.testing.assert_array_equal(lm2, lm[sl]); np.testing.assert_allclose(le2, le[sl], **EVID64)  # (another launch geometry: the fp64 sums run in another order)
     np.testing.assert_allclose(p2, p[sl], rtol=1e-12, atol=1e-15)
     pick = np.random.RandomState(2).choice(n, 40, replace=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
-    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9); np.testing.assert_allclose(le[pick], rle, **EVID)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9); np.testing.assert_allclose(le[pick], rle, **EVID64)
     np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
 
 
@@ -196,7 +214,8 @@ def test_config4_knn_at_its_stated_million_objects():
     (no fit_* / neighbour attributes are kept, as in the reference).  Size-independent properties on every row --
     normalised finite non-negative PDFs, ln-max <= ln-evidence <= ln-max + ln(K k) -- and the first and last 2 000 objects
     against separate 2 000-object calls fed the same Monte-Carlo draws (a k-NN object's result does not depend on its
-    batch: same neighbours, so the same PDFs to rounding and bit-identical ln-max)."""
+    batch: same neighbours, so the same PDFs to rounding and bit-identical ln-max) -- and 40 objects picked across the million
+    against the oracle's exact float64 search."""
     from frankenz_amd import NearestNeighbors
     n, m = 1000000, 100000
     Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m)
@@ -214,6 +233,14 @@ def test_config4_knn_at_its_stated_million_objects():
         assert np.isfinite(pb).all() and pb.min() >= 0
         np.testing.assert_allclose(pb.sum(axis=1), 1.0, rtol=0, atol=1e-12)
         assert np.all(le[sl] >= lm[sl] - 1e-12) and np.all(le[sl] <= lm[sl] + np.log(W) + 1e-9)
+    # oracle: exact float64 search over the same Monte-Carlo feature sets and query draws, 40 objects of the million
+    pick = np.random.RandomState(3).choice(n, 40, replace=False)
+    feats = fo.knn_train(Y, Ye, 25, 'luptitude', np.random.RandomState(1), **fk)
+    q = fo.knn_query_features(X, Xe, 'luptitude', np.random.RandomState(2), **fk)
+    tab = fo.knn_neighbors_exact(feats, q[pick], 20)
+    rp, rlm, rle, rn, rnn, rlnp = fo.knn_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, tab, z, ze, label_dict=od)
+    np.testing.assert_allclose(p[pick], rp, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(lm[pick], rlm, rtol=1e-10); np.testing.assert_allclose(le[pick], rle, rtol=1e-10)
     for sub in (slice(0, 2000), slice(n - 2000, n)):
         nn2 = NearestNeighbors(Y, Ye, Ym, K=25, feature_map='luptitude', fmap_kwargs=fk, rstate=np.random.RandomState(1), verbose=False)
         p2, (lm2, le2) = nn2.fit_predict(X[sub].copy(), Xe[sub].copy(), Xm[sub].copy(), z, ze, rstate=_Slice(np.random.RandomState(2), X, Xe, sub),
@@ -235,8 +262,10 @@ def test_config5_substitute_stack_and_population_likelihood_at_catalogue_scale()
     Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, seed=20261004, varying_errors=True, mask_frac=0.02)
     d, od = dicts()
     bf = BruteForce(Y, Ye, Ym)
+    from frankenz_amd.engine import get_engine
     p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, return_gof=True, save_fits=False,
                                  verbose=False)
+    assert get_engine().last_form() == 'k_hist<screen> (segmented models)'       # per-model errors x unobserved bands: the one-pass kernel
     assert p.shape == (n, 701) and np.isfinite(p).all()
     np.testing.assert_allclose(p.sum(axis=1), 1.0, rtol=0, atol=1e-12)
     stack = p.sum(axis=0)
@@ -260,5 +289,5 @@ def test_config5_substitute_stack_and_population_likelihood_at_catalogue_scale()
     pick = np.random.RandomState(2).choice(n, 60, replace=False)
     rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
     np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
-    np.testing.assert_allclose(le[pick], rle, **EVID)
+    np.testing.assert_allclose(le[pick], rle, **EVID64)
     np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)

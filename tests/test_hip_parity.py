@@ -302,6 +302,22 @@ def test_two_pass_fallback_matches_single_pass():
     close(p2[:40], rp, rtol=1e-8, atol=1e-14)
 
 
+def test_cdf_rule_dropping_half_of_a_hundred_thousand_kernels_is_a_selection_not_a_loop():
+    """a broad posterior with a large cdf_thresh: K ~ n / 2 exclusions over 1e5 kernels -- the arg-max rounds alone would be
+    K n / 64 = 8e7 steps for this ONE row (minutes); the radix selection on the weights' bit patterns takes eight passes"""
+    import time
+    from frankenz_amd import pdf as hp
+    d, od = dicts()
+    rs = np.random.RandomState(78)
+    n = 100000
+    y, ys = rs.uniform(0.5, 6.5, n), rs.uniform(0.02, 0.3, n)
+    wt = rs.permutation(n) + 1.0                                           # distinct
+    t0 = time.perf_counter()
+    got = hp.gauss_kde_dict(d, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=0.5)
+    assert time.perf_counter() - t0 < 5.0
+    close(got, fo.gauss_kde_dict(od, y=y, y_std=ys, y_wt=wt, wt_thresh=None, cdf_thresh=0.5), rtol=1e-9, atol=1e-12)
+
+
 def test_cdf_rule_with_hundreds_of_exclusions():
     """pdf.py:593-597 has no limit on how many of the largest weights the CDF rule drops: a nearly flat weight row over
     4 000 kernels at cdf_thresh 0.1 / 0.5 drops ~400 / ~2 000 of them (until round 4 the kernel refused more than 64),

@@ -5,6 +5,11 @@ set -e
 cd "$(dirname "$0")/../frankenz_amd/csrc"
 OUT=libfrankenz_hip.so
 if [ "$1" = "-o" ]; then OUT=$2; shift 2; fi
+# the band-count units share headers with the main unit (fz_ctx.h holds the context's layout): linking stale ones against a changed
+# header gives a library that reads fields at old offsets (round 5 lost an hour to exactly that)
+for h in fz_ctx.h fz_device.h fz_kernels.h fz_launch.h fz_hist.h fz_nolist.h fz_plane.h fz_modec.h fz_knn.h fz_fastmath.h fz_tables.h fz_inst.hip ../../include/frankenz_hip.h; do
+  if [ "$h" -nt fz_inst_b5.o ]; then echo "mainbuild: $h is newer than the band-count units -- run __graft_entry__.build(force=True)"; exit 1; fi
+done
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form"
 if [ "$OUT" = libfrankenz_hip.so ]; then
   /opt/rocm/bin/hipcc $F -Rpass-analysis=kernel-resource-usage "$@" -c "$PWD/frankenz_hip.hip" -o frankenz_hip.o 2> kernel_resources.txt || { tail -30 kernel_resources.txt; exit 1; }
