@@ -171,7 +171,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     if (!BT) return fail(-5, "fz_models_upload: %d bands unsupported (max 32)", B);
     HIPCHK(hipSetDevice(c->device));
     c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
-    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
+    const int64_t Mp = (M + FZ_MP_ALIGN - 1) / FZ_MP_ALIGN * FZ_MP_ALIGN;      // whole tiles of every kernel (fz_ctx.h)
     const size_t raw = (size_t)M * B * sizeof(double);
     FZCHK(c->d_rx.ensure(raw)); FZCHK(c->d_rxe.ensure(raw)); FZCHK(c->d_rxm.ensure(raw));
     FZCHK(copy_in(c, c->d_rx.p, y, raw)); FZCHK(copy_in(c, c->d_rxe.p, ye, raw)); FZCHK(copy_in(c, c->d_rxm.p, ym, raw));
@@ -252,7 +252,7 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
     if (M <= 0) return fail(-1, "fz_labels_upload_dict: M <= 0");
     HIPCHK(hipSetDevice(c->device));
     c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
-    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
+    const int64_t Mp = (M + FZ_MP_ALIGN - 1) / FZ_MP_ALIGN * FZ_MP_ALIGN;      // whole tiles of every kernel (fz_ctx.h)
     std::vector<int64_t> hy(M), hs(M);
     if (is_device_ptr(y_idx)) {
         HIPCHK(hipMemcpy(hy.data(), y_idx, M * 8, hipMemcpyDeviceToHost));
@@ -398,7 +398,7 @@ extern "C" int fz_labels_upload_grid(fz_ctx* c, const double* y, const double* y
     if (M <= 0 || G <= 1) return fail(-1, "fz_labels_upload_grid: bad sizes");
     HIPCHK(hipSetDevice(c->device));
     c->probe_share = -1.0; c->probe_pending = false;  // what was sampled belongs to the previous model set
-    const int64_t Mp = (M + 1023) / 1024 * 1024;      // FZ_MAX_TILE: the longest LDS tile k_fused stages
+    const int64_t Mp = (M + FZ_MP_ALIGN - 1) / FZ_MP_ALIGN * FZ_MP_ALIGN;      // whole tiles of every kernel (fz_ctx.h)
     FZCHK(c->d_ly.ensure(Mp * 8)); FZCHK(c->d_lstd.ensure(Mp * 8)); FZCHK(c->d_grid.ensure(G * 8));
     FZCHK(c->d_lo.ensure(Mp * 4)); FZCHK(c->d_hi.ensure(Mp * 4)); FZCHK(c->d_norm.ensure(Mp * 8));
     FZCHK(c->d_flags.ensure(64));
@@ -497,7 +497,7 @@ int fz_segments(fz_ctx* c, bool rec0) {
         }
         sstart.push_back((int32_t)perm.size());
         const int32_t last = (int32_t)smask.size() - 1;
-        while (perm.size() % 1024) { perm.push_back(-1); tag.push_back((int32_t)((uint32_t)(last << 16) | 0xc0000000u)); }   // whole tiles (FZ_MAX_TILE)
+        while (perm.size() % FZ_MP_ALIGN) { perm.push_back(-1); tag.push_back((int32_t)((uint32_t)(last << 16) | 0xc0000000u)); }   // whole tiles (FZ_MAX_TILE)
         const int64_t Ms = (int64_t)perm.size();
         if (Ms > M + M / 4 + 4096) return 1;                     // mask patterns as many as models (wide band sets): padding would dominate
         HIPCHK(hipSetDevice(c->device));

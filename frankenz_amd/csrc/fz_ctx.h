@@ -31,6 +31,10 @@ inline int fail(int code, const char* fmt, ...) {
     } while (0)
 #define FZCHK(call) do { int r_ = (call); if (r_ != 0) return r_; } while (0)
 
+// The model arrays are padded to whole LDS tiles of every kernel that stages them: k_fused up to 1024 models, k_hist 256 / 128 / 64
+// or 384 (FZ_HIST_TILE384): the least common multiple
+#define FZ_MP_ALIGN 3072
+
 // ---- grow-only cached device allocation ----------------------------------------
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;

@@ -50,6 +50,19 @@ namespace fz {
 #ifndef FZ_HIST_MP
 #define FZ_HIST_MP 1             // 64-model groups per trip of the model loop
 #endif
+#ifndef FZ_HIST_TILE384
+#define FZ_HIST_TILE384 1        // narrow records (up to 6 doubles): 384-model tiles -- every tile costs ~12 us of prologue per 2.6e10 pairs
+#endif                           // whatever its length (128 / 256 / 384 models: 54.8 / 49.9 / 48.8 ms), and 384 is what fits beside 16 rows
+#ifndef FZ_HIST_REFRESH_TILE
+#define FZ_HIST_REFRESH_TILE 1   // the candidate bar is refreshed at tile ends (tiles 1, 2, 3, then every 5th) instead of by a test in every step
+#endif
+#ifndef FZ_HIST_STAGE_LATE
+#define FZ_HIST_STAGE_LATE 1     // the copy of the next tile is issued AFTER the first group's record reads of the current one (+0.6 %)
+#endif
+#ifndef FZ_HIST_SETTLE2
+#define FZ_HIST_SETTLE2 0        // 1: the screen form settles TWO entries per lane and drain (128 at a time: two independent chains of the
+                                 // exact weight in one basic block), on 192-entry buffers and 128-model tiles (narrow records only)
+#endif
 #ifndef FZ_HIST_SEG_NW0
 #define FZ_HIST_SEG_NW0 16       // segmented form with per-model errors: waves per block
 #endif
@@ -59,9 +72,11 @@ namespace fz {
 #ifndef FZ_HIST_REFRESH
 #define FZ_HIST_REFRESH 32     // steps between two updates of the candidate bar (and flushes of the fp32 partial sums)
 #endif
+// (NEGONLY: the caller's argument cannot exceed a few units -- the settle's -chi2 / 2 + const -- so only the lower clamp is applied)
+template <bool NEGONLY = false>
 __device__ __forceinline__ double exp_small_tab(double x, const double* __restrict__ tab) {
     const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
-    x = vmin_raw(vmax_raw(x, -700.0), 700.0);                     // also maps NaN -> -700
+    x = NEGONLY ? vmax_raw(x, -700.0) : vmin_raw(vmax_raw(x, -700.0), 700.0);      // also maps NaN -> -700
     const double d = fma(x, 369.3299304675746, MAGIC);           // 256 / ln 2
     const double r = fma(d - MAGIC, -0.0027076061740622863, x);  // ln 2 / 256
     const int n = __double2loint(d);
@@ -85,6 +100,11 @@ __device__ __forceinline__ double sqrt_nr(double r) {
     s = fma(fma(-s, s, r), hy, s);
     return s;
 }
+// ln of the small integers the band counts give (constant expressions: the compiler has no constexpr log)
+constexpr double hist_ln(double k) {
+    return k == 1.0 ? 0.0 : k == 2.0 ? 0.6931471805599453 : k == 3.0 ? 1.0986122886681098 : k == 4.0 ? 1.3862943611198906
+         : k == 5.0 ? 1.6094379124341003 : k == 6.0 ? 1.791759469228055 : k == 7.0 ? 1.9459101090932196 : 2.0794415416798357;
+}
 // w = L(chi2) / L(K) = (chi2 / K)^(K/2) exp(-(chi2 - K) / 2), all fp64: integer powers by multiplication,
 // the half power by a Newton-refined v_rsq_f64, one exp, no log
 template <int WP, bool SMALL = false>
@@ -101,6 +121,36 @@ __device__ __forceinline__ double hist_exactw(double c2, const FastTabs& tb) {
         double base = r;
 #pragma unroll
         for (int e = WP >> 1; e > 0; e >>= 1) { if (e & 1) pw = pw * base; base = base * base; }
+    }
+    if constexpr (SMALL && (WP >> 1) <= 3) {
+        // the settle of the screen form (chi2 > 0 always: a zero never reaches the buffer): the constant K^(-K/2) e^(K/2) rides in the
+        // exponential's argument, so the powers are those of chi2 itself -- c2^(K div 2), times sqrt(c2) without the zero guard --
+        // one multiplication, one maximum and one minimum fewer per settled pair than the general form below
+        double q = 1.0;
+        if constexpr ((WP >> 1) >= 1) q = c2;
+        if constexpr ((WP >> 1) >= 2) q = q * c2;
+        if constexpr ((WP >> 1) >= 3) q = q * c2;
+        if constexpr (WP & 1) {
+            const double y = __builtin_amdgcn_rsq(c2), hy = 0.5 * y;
+            double sq = c2 * y;
+            sq = fma(fma(-sq, sq, c2), hy, sq);
+            sq = fma(fma(-sq, sq, c2), hy, sq);
+            q = (WP >> 1) ? q * sq : sq;
+        }
+        constexpr double EK = 0.5 * K - 0.5 * K * hist_ln(K);      // ln of K^(-K/2) e^(K/2)
+        return q * exp_small_tab<true>(fma(c2, -0.5, EK), tb.expt);
+    }
+    if constexpr (!SMALL && (WP >> 1) <= 3) {
+        // the direct form: the same folding (so that the two forms build a pair's weight from the same factors: an object's ln-max then
+        // does not depend on which form its launch took beyond the exponential's own rounding); the root keeps its zero guard here --
+        // this form weighs EVERY pair, a chi2 of exactly 0 (a self match) included, and must give exactly 0 for it
+        double q = 1.0;
+        if constexpr ((WP >> 1) >= 1) q = c2;
+        if constexpr ((WP >> 1) >= 2) q = q * c2;
+        if constexpr ((WP >> 1) >= 3) q = q * c2;
+        if constexpr (WP & 1) q = (WP >> 1) ? q * sqrt_nr(c2) : sqrt_nr(c2);
+        constexpr double EK = 0.5 * K - 0.5 * K * hist_ln(K);
+        return q * exp_neg(fma(c2, -0.5, EK), tb);
     }
     if constexpr (WP & 1) pw = pw * sqrt_nr(r);           // chi2 == 0 (self match): weight 0
     const double w = pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
@@ -128,12 +178,12 @@ __device__ __forceinline__ double hist_exactw_rt(double c2, int wp, const FastTa
 // no branch but the wave-uniform one around the square root; r^3.5 e^-700 cannot overflow, so the clamp's guard is not needed
 template <bool SMALL = false>
 __device__ __forceinline__ double hist_exactw_rt8(double c2, int wp, double K, double rK, const FastTabs& tb) {
-    if (wp == 0) return SMALL ? exp_small_tab(-0.5 * c2, tb.expt) : exp_clamped(-0.5 * c2, tb);      // wave-uniform branch
+    if (wp == 0) return SMALL ? exp_small_tab<true>(-0.5 * c2, tb.expt) : exp_clamped(-0.5 * c2, tb);      // wave-uniform branch
     const double r = c2 * rK, r2 = r * r;
     const int h = wp >> 1;
     double pw = ((h & 1) ? r : 1.0) * ((h & 2) ? r2 : 1.0);
     if (wp & 1) pw = pw * sqrt_nr(r);
-    return pw * (SMALL ? exp_small_tab(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
+    return pw * (SMALL ? exp_small_tab<true>(fma(c2, -0.5, 0.5 * K), tb.expt) : exp_clamped(fma(c2, -0.5, 0.5 * K), tb));
 }
 
 // models per LDS tile by record width: two tiles, the histograms and the candidate buffers share 160 KB
@@ -141,6 +191,8 @@ template <class SRC>
 constexpr int hist_tile() {
     // 16 waves per block (up to 8 bands): 256-model tiles up to 10 doubles per record, 128 beyond (6-8 bands with per-model errors:
     // 14-18 doubles); 8 waves per block (the wide instantiations): 256 up to 18 doubles, 128 up to 34, 64 beyond
+    if (FZ_HIST_SETTLE2 && SRC::NB <= 8 && SRC::RW <= 6 && SRC::LMODE == 1) return 128;      // (room for the 192-entry buffers; the tile barrier costs nothing)
+    if (FZ_HIST_TILE384 && SRC::NB <= 8 && SRC::RW <= 6) return 384;                          // narrow records: the longest tile the LDS holds beside 16 rows
     if (SRC::NB <= 8) return (SRC::RW <= 10 && !(SRC::LMODE == 2 && SRC::RW > 6)) ? 256 : 128;   // (free scale at 7 / 8 bands: the model-number buffer is twice the size)
     return SRC::RW <= 18 ? 256 : (SRC::RW <= 34 ? 128 : 64);
 }
@@ -234,7 +286,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     bool kok = true;                                                    // OBJK: the object's power is >= 1 (else: the exact sweep)
     double lgq = src_.lp.lg_full;
     constexpr int NOBJ = NW * TW;
-    constexpr int CAP = 128, DTHR = CAP - 64;                             // ring entries per object; drain from DTHR pending entries on
+    constexpr bool S2 = (FZ_HIST_SETTLE2 == 1) && !EXACT && SRC::NB <= 8 && SRC::RW <= 6 && SRC::LMODE == 1;      // two entries per lane and drain
+    constexpr int CAP = S2 ? 192 : 128, DTHR = CAP - 64;                  // ring entries per object; drain from DTHR pending entries on
     using tag_t = uint16_t;                                               // label index (< 65536, checked by the launcher)
     static_assert(WP >= 1 && WP <= 30, "chi2^(1/2) ... chi2^15");
     __shared__ __attribute__((aligned(16))) double tileA[TD];
@@ -455,6 +508,41 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         };
         // settle the LAST (up to) 64 entries of object o's buffer with all lanes (their order does not matter: nothing has to move)
         auto drain = [&](int o, auto badc) {
+            if constexpr (S2) {
+                // the last (up to) 128 entries, two per lane: the two exact weights are independent chains in one basic block (a single
+                // chain of ~35 dependent fp64 operations left the vector pipe idle a third of the time at four waves per SIMD)
+                const int n = hs.pend[o] < 128 ? hs.pend[o] : 128;
+                const int rest = hs.pend[o] - n;
+                const double ca = rc2[o * CAP + rest + lane], cb = rc2[o * CAP + rest + 64 + lane];
+                const int ta = (int)rtag[o * CAP + rest + lane], tb2 = (int)rtag[o * CAP + rest + 64 + lane];
+                const bool aa = lane < n, ab = lane + 64 < n;
+                double wa, wb;
+                if (decltype(badc)::value && segbad) {
+                    wa = aa ? exp_clamped(seg_lnl(ca, ndcur) - lref, tb) : 0.0; wb = ab ? exp_clamped(seg_lnl(cb, ndcur) - lref, tb) : 0.0;
+                } else {
+                    wa = exactw_tab(ca, tbx, std::true_type{}); wb = exactw_tab(cb, tbx, std::true_type{});
+                    wa = aa ? wa : 0.0; wb = ab ? wb : 0.0;
+                }
+                if constexpr (SEG) { wa *= fk; wb *= fk; }
+                hs.Sc[o] += wa + wb;
+                hs.wmx[o] = vmax_raw(hs.wmx[o], vmax_raw(wa, wb));
+                if (wa > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + ta + w0], wa);
+                if (wb > thr_def) unsafeAtomicAdd(&rows[o * acc_stride + tb2 + w0], wb);
+                const bool ama = aa && !(wa > thr_def) && wa > hs.wamb[o], amb = ab && !(wb > thr_def) && wb > hs.wamb[o];
+                const unsigned long long ma = __ballot(ama), mb = __ballot(amb);
+                if (ma | mb) {                                      // wave-uniform, rare
+                    const int na = __builtin_popcountll(ma), nb = __builtin_popcountll(mb);
+                    if (hs.namb[o] >= 0 && hs.namb[o] + na + nb <= cap) {
+                        const int pa = __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+                        const int pb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+                        if (ama) { Cand e; e.lnl = ca; e.j = ta; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pa] = e; }
+                        if (amb) { Cand e; e.lnl = cb; e.j = tb2; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + na + pb] = e; }
+                        hs.namb[o] += na + nb;
+                    } else hs.namb[o] = -1;
+                }
+                hs.pend[o] = rest;
+                return;
+            }
             const int n = hs.pend[o] < 64 ? hs.pend[o] : 64;
             const int rest = hs.pend[o] - n;                      // < 64
             double c2 = rc2[o * CAP + rest + lane];
@@ -578,6 +666,19 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 segcur = -1;
             }
         }
+        // the bars follow the wave-wide best weight seen
+        auto refresh_bars = [&]() {
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                const float mx = wave_maxf_dpp(hs.tmax[o]);
+                hs.tmax[o] = mx;
+                hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
+                if constexpr (SEG) hs.tthr[o] = segbad ? -INFINITY : hs.tthr[o];
+                // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
+                // what still waits in the buffer only raises it)
+                hs.wamb[o] = wave_max_pos_hi(hs.wmx[o]) * (wt_thresh * 0.999);
+            }
+        };
         // one 64-model group against the wave's objects, records and label words in registers.  SLOW: the group may hold pad slots of
         // a segment (SEG, tiles in which the mask pattern changes)
         constexpr int MP = EXACT ? 1 : FZ_HIST_MP;
@@ -653,17 +754,10 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #endif
                             hs.pend[o] += __builtin_popcountll(mask);
                         }
-                        if (++hs.tick == hs.next) {                               // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
-                            hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
-#pragma unroll
-                            for (int o = 0; o < TW; ++o) {
-                                const float mx = wave_maxf_dpp(hs.tmax[o]);       // the bars follow the wave-wide best weight seen
-                                hs.tmax[o] = mx;
-                                hs.tthr[o] = mx + (ldrop0 - 2.f * tmarg);       // (the best's t and the pair's t each carry the margin)
-                                if constexpr (SEG) hs.tthr[o] = segbad ? -INFINITY : hs.tthr[o];
-                                // the ambiguous band starts at wt_thresh x the best EXACT weight settled so far (a lower bound of the final best:
-                                // what still waits in the buffer only raises it)
-                                hs.wamb[o] = wave_max_pos_hi(hs.wmx[o]) * (wt_thresh * 0.999);
+                        if constexpr (!FZ_HIST_REFRESH_TILE) {
+                            if (++hs.tick == hs.next) {                           // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th
+                                hs.next = hs.tick < 16 ? 2 * hs.tick : hs.tick + FZ_HIST_REFRESH;
+                                refresh_bars();
                             }
                         }
 #pragma unroll
@@ -682,7 +776,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         auto run_tile = [&](const double* cur, double* nxt, int t, auto tailc, auto slowc) {
             constexpr bool TAIL = decltype(tailc)::value;
             constexpr bool pure = !decltype(slowc)::value;
-            if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave);
+            constexpr bool LATE = FZ_HIST_STAGE_LATE && pure && hist_prefetch<SRC>() && !(SEG && SRC::NB + SRC::NVAL > FZ_HIST_SEG_PFMAX);
+            if (!LATE || !work) { if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave); }
             if (work) {
                 const int32_t* tags = reinterpret_cast<const int32_t*>(cur + TDR);
                 // MP 64-model groups per trip: their chi2 chains and weights sit in one basic block (the appends, which
@@ -701,6 +796,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             tagn[q] = tags[q * 64 + lane];
                         }
                     }
+                    if constexpr (LATE) { if (t + 1 < ntiles) nl_stage_tile<SRC, TILE, NT, true>(src, posw, t + 1, nxt, tid, wave); }
 #pragma unroll
                     for (int st = 0; st < TILE / 64; st += MP) {
                         typename SRC::MR m[MP];
@@ -743,6 +839,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         }
                     }
                 }
+                if constexpr (FZ_HIST_REFRESH_TILE && !EXACT) {
+                    if (++hs.tick == hs.next) { hs.next = hs.tick < 3 ? hs.tick + 1 : hs.tick + 5; refresh_bars(); }
+                }
             }
 #if !defined(FZ_DIAG_NOBARRIER)
             __syncthreads();
@@ -763,7 +862,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             // there is no partial tile.  (Every wave stages and meets the barrier once per tile whichever way it takes.)
             auto tile_pure = [&](const double* cur) -> bool {
                 if (!work) return true;
-                const int wv = (reinterpret_cast<const int32_t*>(cur + TDR)[(lane & (TILE / 64 - 1)) * 64] >> 16) & 0x7fff;      // (segment | pad-slots flag << 14) of group lane mod 4
+                const int wv = (reinterpret_cast<const int32_t*>(cur + TDR)[(lane % (TILE / 64)) * 64] >> 16) & 0x7fff;      // (segment | pad-slots flag << 14) of group lane mod 4
                 return __ballot(wv != segcur) == 0ull && !segbad;          // (segcur never carries the flag; a pattern without a mode: group by group)
             };
             int t = 0;

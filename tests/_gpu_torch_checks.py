@@ -151,7 +151,10 @@ def check_overlapped_rounds_through_rccl_on_one_rank():
         assert sharded.last_stats['world'] == 1 and sharded.last_stats['chunks'] == chunks
         torch.cuda.synchronize()
         np.testing.assert_allclose(q.cpu().numpy(), p, rtol=1e-12, atol=1e-16, equal_nan=True)
-        np.testing.assert_array_equal(qm.cpu().numpy(), lm)
+        # (the one call of 30 011 objects samples how broad the likelihoods are and may take the direct form; the rounds are too short
+        #  to sample and take the screen form: the two form the best weight by different -- equally exact -- fp64 expressions, so
+        #  ln-max agrees to two ulps, not bit for bit)
+        np.testing.assert_allclose(qm.cpu().numpy(), lm, rtol=1e-14, equal_nan=True)
         np.testing.assert_allclose(qe.cpu().numpy(), le, rtol=1e-12, equal_nan=True)
     # NumPy in, NumPy out (the caller's arrays get the in-place clean)
     Xc = X.copy()

@@ -52,7 +52,9 @@ def test_sharded_hip_matches_the_unsharded_call(name, world, tmp_path):
     res = run_ranks(name, world, tmp_path)
     for r, out in enumerate(res):
         np.testing.assert_allclose(out['pdfs'], p, rtol=1e-12, atol=1e-16, equal_nan=True)
-        np.testing.assert_array_equal(out['lmap'], lm)
+        # (ln-max: ln L(mode) + ln of the best exact weight -- bit for bit when both launches take the same kernel form, two ulps when the
+        #  sampled breadth of the likelihoods sends one of them to the direct form and the other to the screen form)
+        np.testing.assert_allclose(out['lmap'], lm, rtol=1e-14, equal_nan=True)
         np.testing.assert_allclose(out['levid'], le, equal_nan=True, **EVID)
         assert out['pdfs'].shape == p.shape
         np.testing.assert_allclose(out['stack'], np.nansum(p, axis=0), rtol=1e-11, atol=1e-14)
