@@ -189,46 +189,6 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     int it_max = 0;
     const int want_lnl_only = c->mc_lnl_only;
     c->mc_lnl_only = 0;                                  // honoured below by the one-block-per-object path only (and not for neighbour subsets)
-    if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
-        if (want_lnl_only && !sub.nbr && !getenv("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
-        // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
-        auto launch = [&](auto kern, int T, size_t lds, const int* list, int64_t nobj) -> int {
-            HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int bpc = 1;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, T, lds));
-            const int64_t blocks = std::min<int64_t>(nobj, (int64_t)std::max(1, bpc) * c->cu_count);
-            ModeCState s2 = st; s2.last_iter = counts + 2; s2.list = list; s2.namb = counts + 3;
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c->stream, mc, s2, nobj, (int)M, o->ltol, max_iter, counts + 1);
-            return 0;
-        };
-        auto run = [&](auto fastc, const int* list, int64_t nobj) -> int {
-            constexpr bool F = decltype(fastc)::value;
-            using MCT = ModeC<BT, MASKED>;
-            const size_t lds = (size_t)M * 8;                    // the previous scale of every model
-            if (M <= 1024) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, lds, list, nobj); }
-            if (M <= 4096) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, lds, list, nobj); }
-            if (M <= 768 * 14) { c->mc_info[3] = 768; return launch(k_modec_persist<MCT, F, 768, 14>, 768, lds, list, nobj); }
-            c->mc_info[3] = 512;
-            return launch(k_modec_persist<MCT, F, 512, 32>, 512, lds, list, nobj);
-        };
-        if (fast) FZCHK(run(std::true_type{}, nullptr, n)); else FZCHK(run(std::false_type{}, nullptr, n));
-        int res[3] = {0, 0, 0};                              // status, slowest object's iterations, ambiguous objects
-        HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        const int namb = res[2];
-        if (fast && namb > 0 && !res[0]) {
-            FZCHK(run(std::false_type{}, st.amb, namb));
-            HIPCHK(hipMemcpyAsync(res, counts + 1, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            res[2] = namb;
-        }
-        HIPCHK(hipGetLastError());
-        if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
-                                    "(the reference loop at pdf.py:199 would not terminate)", max_iter);
-        c->mc_info[0] += fast ? res[2] : 0; c->mc_info[1] = std::max<int64_t>(c->mc_info[1], res[1]); c->mc_info[2] = 1;
-        c->tm.n_modec += res[1];         // iterations of the slowest object (the two timed scopes add the other two counts the bench subtracts)
-        return 0;
-    }
     // one run of the fixed point over `n0` objects (all of the chunk, or the listed ones), to convergence
     auto iterate = [&](const int* list0, int n0, bool fst) -> int {
         auto step = [&](const ModeCState& s2, int nobj, int init) {
@@ -261,6 +221,103 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
         }
         return 0;
     };
+    // beyond FZ_MCP_MAXM models (mask-free tame data): k_modec_rounds with the scales in the scale plane instead of LDS -- no limit on M;
+    // objects it hands back are redone by the state-plane kernels with IEEE divisions
+    {
+        const char* ev = getenv("FZ_MODEC_ROUNDS");
+        if (fast && M > FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES") && !(ev && ev[0] == '0')) {
+            using MCT = ModeC<BT, MASKED>;
+            if constexpr (!MASKED) {
+                HIPCHK(hipMemsetAsync(counts + 4, 0, 4, c->stream));
+                int bpc = 1;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)k_modec_rounds<MCT, 512, false>, 512, 0));
+                const int64_t blocks = std::min<int64_t>(n, (int64_t)std::max(1, bpc) * c->cu_count);
+                ModeCState s2 = st; s2.last_iter = counts + 2; s2.list = nullptr; s2.namb = counts + 3; s2.qhead = counts + 4;
+                hipLaunchKernelGGL((k_modec_rounds<MCT, 512, false>), dim3((unsigned)blocks), dim3(512), 0, c->stream, mc, s2, n, (int)M, o->ltol,
+                                   max_iter, counts + 1);
+                int res[3] = {0, 0, 0};
+                HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
+                                            "(the reference loop at pdf.py:199 would not terminate)", max_iter);
+                int slow = res[1];
+                if (res[2] > 0) {
+                    HIPCHK(hipMemsetAsync(st.err, 0, n * 8, c->stream));
+                    HIPCHK(hipMemsetAsync(counts + 2, 0, 4, c->stream));
+                    FZCHK(iterate(st.amb, res[2], false));
+                    int it2 = 0;
+                    HIPCHK(hipMemcpyAsync(&it2, counts + 2, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    slow = std::max(slow, it2 + 1);
+                }
+                HIPCHK(hipGetLastError());
+                c->mc_info[0] += res[2]; c->mc_info[1] = std::max<int64_t>(c->mc_info[1], slow); c->mc_info[2] = 3; c->mc_info[3] = 512;
+                c->tm.n_modec += slow;
+                return 0;
+            }
+        }
+    }
+    if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
+        if (want_lnl_only && !sub.nbr && !getenv("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
+        // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
+        auto launch = [&](auto kern, int T, size_t lds, const int* list, int64_t nobj) -> int {
+            HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int bpc = 1;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, T, lds));
+            const int64_t blocks = std::min<int64_t>(nobj, (int64_t)std::max(1, bpc) * c->cu_count);
+            ModeCState s2 = st; s2.last_iter = counts + 2; s2.list = list; s2.namb = counts + 3; s2.qhead = counts + 4;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c->stream, mc, s2, nobj, (int)M, o->ltol, max_iter, counts + 1);
+            return 0;
+        };
+        auto run = [&](auto fastc, const int* list, int64_t nobj) -> int {
+            constexpr bool F = decltype(fastc)::value;
+            using MCT = ModeC<BT, MASKED>;
+            const size_t lds = (size_t)M * 8;                    // the previous scale of every model
+            if constexpr (F && !MASKED) {
+                // several iterations per record read (k_modec_rounds); FZ_MODEC_ROUNDS=0: one iteration per read (k_modec_persist)
+                const char* ev = getenv("FZ_MODEC_ROUNDS");
+                if (!(ev && ev[0] == '0')) {
+                    c->mc_info[2] = 3;
+                    HIPCHK(hipMemsetAsync(counts + 4, 0, 4, c->stream));
+                    const int shape = getenv("FZ_MCR_SHAPE") ? atoi(getenv("FZ_MCR_SHAPE")) : 0;
+                    if (shape == 1) { c->mc_info[3] = 256; return launch(k_modec_rounds<MCT, 256, false>, 256, 0, list, nobj); }
+                    if (shape == 2) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, false>, 512, 0, list, nobj); }
+                    if (shape == 3) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, true>, 512, lds, list, nobj); }
+                    if (M <= 1024) { c->mc_info[3] = 256; return launch(k_modec_rounds<MCT, 256, true>, 256, lds, list, nobj); }
+                    if (M <= 4096) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, true>, 512, lds, list, nobj); }
+                    c->mc_info[3] = 1024;
+                    return launch(k_modec_rounds<MCT, 1024, true>, 1024, lds, list, nobj);
+                }
+            }
+            if (M <= 1024) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 1>, 1024, lds, list, nobj); }
+            if (M <= 4096) { c->mc_info[3] = 1024; return launch(k_modec_persist<MCT, F, 1024, 4>, 1024, lds, list, nobj); }
+            if (M <= 768 * 14) { c->mc_info[3] = 768; return launch(k_modec_persist<MCT, F, 768, 14>, 768, lds, list, nobj); }
+            c->mc_info[3] = 512;
+            return launch(k_modec_persist<MCT, F, 512, 32>, 512, lds, list, nobj);
+        };
+        c->mc_info[2] = 1;
+        if (fast) FZCHK(run(std::true_type{}, nullptr, n)); else FZCHK(run(std::false_type{}, nullptr, n));
+        const int64_t kind = c->mc_info[2], tpb = c->mc_info[3];            // (the re-run below is not what the call is reported as)
+        int res[3] = {0, 0, 0};                              // status, slowest object's iterations, ambiguous objects
+        HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int namb = res[2];
+        const bool trace = getenv("FZ_MODEC_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "mode C: first launch done: status %d, slowest object %d iterations, %d objects handed to the IEEE kernel\n", res[0], res[1], res[2]);
+        if (fast && namb > 0 && !res[0]) {
+            FZCHK(run(std::false_type{}, st.amb, namb));
+            HIPCHK(hipMemcpyAsync(res, counts + 1, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            res[2] = namb;
+            if (trace) fprintf(stderr, "mode C: IEEE launch done: status %d, slowest object %d iterations\n", res[0], res[1]);
+        }
+        HIPCHK(hipGetLastError());
+        if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
+                                    "(the reference loop at pdf.py:199 would not terminate)", max_iter);
+        c->mc_info[0] += fast ? res[2] : 0; c->mc_info[1] = std::max<int64_t>(c->mc_info[1], res[1]); c->mc_info[2] = kind; c->mc_info[3] = tpb;
+        c->tm.n_modec += res[1];         // iterations of the slowest object (the two timed scopes add the other two counts the bench subtracts)
+        return 0;
+    }
     FZCHK(iterate(nullptr, (int)n, fast));
     int namb = 0;
     if (fast) {

@@ -46,6 +46,7 @@ struct ModeCState {
     // and s / c / sh are not written at all (three 8 B-per-pair planes and the k_modec_final pass less)
     int lnl_only;
     const double* lgtab;
+    int* qhead;                // (1) k_modec_rounds: the next object of the launch (zeroed by the host)
     int* niter;                // (Nc) iterations each object took (the count of pdf.py:199's loop passes); may be nullptr
 };
 
@@ -62,6 +63,7 @@ struct ModeC {
 
     // one solve of (scale, chi2, lnl) for variance var_b = xe2_b + (s_prev*ye_b)^2;
     // s_prev = 1 gives the initial pass of pdf.py:171-194.
+    static constexpr int NB = BT;
     static constexpr int REC_W = 2 * BT + ((6 - (2 * BT) % 4) % 4);       // doubles per row of the array-of-records copy (fluxes | squared errors | pad)
     __device__ __forceinline__ void load_rec(int64_t j, double (&rec)[REC_W]) const {
         const double2* rp = reinterpret_cast<const double2*>(mv.rec0) + (uint32_t)j * (uint32_t)(REC_W / 2);
@@ -71,15 +73,22 @@ struct ModeC {
     // the FAST solve on a record already in registers (fluxes | squared errors), see solve<true>
     __device__ __forceinline__ void solve_rec(int64_t i, const double (&rec)[REC_W], double sprev, double& s, double& lnl,
                                               double& chi2, double& shape, const double2* lt) const {
-        double rv[BT], y[BT], x[BT];
+        double x[BT], v[BT];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) { x[b] = ov.x[i * BT + b]; v[b] = ov.v[i * BT + b]; }
+        solve_xv(x, v, rec, sprev, s, lnl, chi2, shape, lt);
+    }
+    // ... and with the object's row (fluxes x, variances v = xe^2) in registers too: k_modec_rounds runs several solves on one record
+    __device__ __forceinline__ void solve_xv(const double (&x)[BT], const double (&v)[BT], const double (&rec)[REC_W], double sprev,
+                                             double& s, double& lnl, double& chi2, double& shape, const double2* lt) const {
+        double rv[BT], y[BT];
         double inter = 0.0; shape = 0.0;
         double vprod = 1.0; int vexp = 0;
         const double s2 = sprev * sprev;
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
             y[b] = rec[b];
-            x[b] = ov.x[i * BT + b];
-            const double var = fma(s2, rec[BT + b], ov.v[i * BT + b]);   // xe^2 + s^2 ye^2
+            const double var = fma(s2, rec[BT + b], v[b]);              // xe^2 + s^2 ye^2
             rv[b] = rcp_nr<2>(var);
             const double yr = y[b] * rv[b];
             inter = fma(yr, x[b], inter);
@@ -293,6 +302,151 @@ __global__ __launch_bounds__(FZ_MCP_T) void k_modec_persist(MC mc, ModeCState st
             }
         }
         if (tid == 0) { atomicMax(st.last_iter, iters); if (st.niter) st.niter[i] = iters; }
+        __syncthreads();
+    }
+}
+
+// ---- rounds: several iterations per record read (round 5; mask-free tame data, the FAST solve) ----
+// k_modec_persist re-reads every model record from L2 on every iteration: 580 GB of L2 -> CU traffic on the 2e4 x 1e4 benchmark,
+// waves waiting 46 % of their cycles (profiles/r5_v1_pmc_modeC.txt).  But a model's trajectory s_0 -> s_1 -> ... depends on
+// nothing but its own record; only the STOP rule couples the models.  So a thread takes one of its models, reads the record ONCE
+// and runs R iterations on it, noting per iteration whether its error was above ltol (a bit per iteration); the block then ANDs
+// the bits: the reference stops at the first iteration t* at which no model was above ltol.  R is chosen so that t*, if it comes
+// in this round at all, is the round's LAST iteration: the errors decay geometrically, the round's last errors give the rate, and
+// the round after covers the predicted remainder (the slower of the last two rates, 0.8 of it in the first passes; never too
+// long on 880 traced objects of the benchmark and of the tests, docs/modec.md).  A round that turns out too long -- t* before
+// its end: the models have moved past the state the reference returns -- hands the object to the IEEE instantiation of
+// k_modec_persist, as the interval guard does for an error within rounding of ltol (st.amb): exact, rare, ~2 x the cost.
+// Between rounds the scale of every model sits in LDS and its ln-like in the output plane (L2); chi2 and shape of a round's last
+// solve are written every round (8 / 16 B per model: which round is the last is known only afterwards).
+// Per iteration and pair that is 1 / R record reads (R ~ 4.6 on the benchmark) and no block reduction; no per-thread state arrays:
+// <= 128 VGPRs at any model count.
+#define FZ_MCR_RMAX 16
+// SLDS: the scales between rounds in LDS (8 B per model: M <= FZ_MCP_MAXM, one block per CU beyond ~9 000 models) or in the
+// scale plane (any M, several small blocks per CU).  Objects are taken from a queue (st.qhead): iteration counts differ by
+// two orders of magnitude from object to object, a fixed share per block would leave the chip waiting for the unluckiest block.
+template <class MC, int TPB, bool SLDS>
+__global__ __launch_bounds__(TPB) void k_modec_rounds(MC mc, ModeCState st, int64_t Nc, int M, double ltol, int max_iter, int* status) {
+    extern __shared__ double s_cur[];                     // SLDS: [M] the scale of every model after the last round
+    __shared__ double red[4][TPB / 64];
+    __shared__ unsigned redm[2][TPB / 64];
+    __shared__ int s_ctl[3];                              // what the block does next (0 stop, 1 go on, 2 hand over, 3 not converged), length of the next round, next object
+    __shared__ __attribute__((aligned(16))) double s_logt[256];
+    constexpr int BT = MC::NB;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 256; k += TPB) s_logt[k] = FZ_LOG_TAB[k];
+    const double2* lt = reinterpret_cast<const double2*>(s_logt);
+    __syncthreads();
+    while (true) {
+        if (tid == 0) s_ctl[2] = atomicAdd(st.qhead, 1);
+        __syncthreads();
+        const int64_t slot = __builtin_amdgcn_readfirstlane(s_ctl[2]);          // (block-uniform, and the compiler is told so)
+        if (slot >= Nc) break;
+        const int64_t i = st.list ? (int64_t)st.list[slot] : slot;
+        const int Mi = mc.sub.nnb ? (int)(mc.sub.nnb[i] < M ? mc.sub.nnb[i] : M) : M;
+        double x[BT], v[BT];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) { x[b] = mc.ov.x[i * BT + b]; v[b] = mc.ov.v[i * BT + b]; }
+        int iters = 0, R = max_iter < 2 ? 1 : 2, f = 0;       // (iters: thread 0 counts, only it uses the count)
+        bool first = true;
+#ifdef FZ_MCR_DEBUG
+        int dbg_rounds = 0;
+#endif
+        double h0 = 0.0, h1 = 0.0, h2 = 0.0;              // thread 0: the last three errors E(t) = max_j (lower bound of |dlnl_j|)
+        while (true) {
+            double elast = 0.0, eprev = 0.0, eprev2 = 0.0, ehlast = 0.0;
+            unsigned above = 0, fnan = 0;                   // bit r: this thread had a model above ltol / model 0's error was NaN at the round's iteration r
+            for (int j = tid; j < Mi; j += TPB) {
+                const int64_t k = i * M + j;
+                double rec[MC::REC_W];
+                mc.load_rec(mc.sub.nbr ? mc.sub.nbr[i * mc.sub.W + j] : (int64_t)j, rec);
+                double s, l, c = 0.0, sh = 0.0;
+                if (first) mc.solve_xv(x, v, rec, 1.0, s, l, c, sh, lt);      // the initial pass of pdf.py:171-194
+                else { s = SLDS ? s_cur[j] : st.s[k]; l = st.l[k]; }
+                for (int r = 0; r < R; ++r) {
+                    double sn, ln;
+                    mc.solve_xv(x, v, rec, s, sn, ln, c, sh, lt);
+                    double ej = fabs(ln - l);
+                    if (j == 0 && ej != ej) fnan |= 1u << r;
+                    const double dl = 2.9e-14 * (fabs(ln) + fabs(l));         // what the IEEE iterates could differ by (k_modec_persist)
+                    const double ehj = ej + dl;
+                    ej = fmax(ej - dl, 0.0);                                  // (a NaN becomes 0: dropped, as by the builtin max)
+                    if (ej > ltol) above |= 1u << r;
+                    if (r == R - 1) { elast = fmax(elast, ej); if (ehj == ehj) ehlast = fmax(ehlast, ehj); }
+                    else if (r == R - 2) eprev = fmax(eprev, ej);
+                    else if (r == R - 3) eprev2 = fmax(eprev2, ej);
+                    s = sn; l = ln;
+                }
+                if (SLDS) s_cur[j] = s; else st.s[k] = s;
+                st.l[k] = l;
+                if (st.lnl_only != 1) st.c[k] = c;
+                if (!st.lnl_only) st.sh[k] = sh;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                elast = fmax(elast, __shfl_xor(elast, o, 64)); eprev = fmax(eprev, __shfl_xor(eprev, o, 64));
+                eprev2 = fmax(eprev2, __shfl_xor(eprev2, o, 64)); ehlast = fmax(ehlast, __shfl_xor(ehlast, o, 64));
+                above |= (unsigned)__shfl_xor((int)above, o, 64); fnan |= (unsigned)__shfl_xor((int)fnan, o, 64);
+            }
+            if ((tid & 63) == 0) {
+                red[0][tid >> 6] = elast; red[1][tid >> 6] = eprev; red[2][tid >> 6] = eprev2; red[3][tid >> 6] = ehlast;
+                redm[0][tid >> 6] = above; redm[1][tid >> 6] = fnan;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double E = 0.0, E1 = 0.0, E2 = 0.0, EH = 0.0; unsigned ab = 0, fn = 0;
+                for (int w = 0; w < TPB / 64; ++w) {
+                    E = fmax(E, red[0][w]); E1 = fmax(E1, red[1][w]); E2 = fmax(E2, red[2][w]); EH = fmax(EH, red[3][w]);
+                    ab |= redm[0][w]; fn |= redm[1][w];
+                }
+                const unsigned all = (R >= 32) ? 0xffffffffu : ((1u << R) - 1u);
+                const unsigned stop = (~ab | fn) & all;                       // `while lerr > ltol`: the iterations after which the reference stops
+                if (R >= 3) { h0 = E2; h1 = E1; h2 = E; } else if (R == 2) { h0 = h2; h1 = E1; h2 = E; } else { h0 = h1; h1 = h2; h2 = E; }
+                iters += R;
+                int g, Rn = 1;
+                if (stop) {
+                    const int ts = __builtin_ctz(stop);
+                    if (ts != R - 1) g = 2;                                   // the round ran past the stop: the IEEE kernel redoes the object
+                    else g = (!((fn >> ts) & 1u) && EH > ltol) ? 2 : 0;       // ltol inside the interval of the error: the IEEE iterates decide
+                } else if (iters >= max_iter) g = 3;
+                else {
+                    g = 1;
+                    // remaining iterations if the errors keep their rate: the slower of the last two rates; 0.8 of it in the first passes
+                    double n = 1.0;
+                    if (h2 < h1 && h2 > 0.0) {
+                        double rho = h2 / h1;
+                        if (iters >= 3 && h1 < h0) rho = fmax(rho, h1 / h0);
+                        n = log(ltol / h2) / log(rho);
+                        if (iters < 6) n *= 0.8;
+                    }
+                    Rn = (n >= (double)FZ_MCR_RMAX) ? FZ_MCR_RMAX : ((n >= 1.0) ? (int)n : 1);      // (NaN: 1)
+                    if (Rn > max_iter - iters) Rn = max_iter - iters;
+                }
+#ifdef FZ_MCR_DEBUG
+                if (++dbg_rounds <= 40 || dbg_rounds % 100 == 0 || g != 1)
+                    printf("obj %d round %d: R %d iters %d E %.3e E1 %.3e EH %.3e ab %x fn %x stop %x -> g %d Rn %d\n", (int)i, dbg_rounds, R, iters, E, E1, EH, ab, fn, stop, g, Rn);
+                if (dbg_rounds > 20000) g = 3;
+#endif
+                s_ctl[0] = g; s_ctl[1] = Rn;
+            }
+            __syncthreads();
+            f = __builtin_amdgcn_readfirstlane(s_ctl[0]); R = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+            first = false;
+            __syncthreads();
+            if (f != 1) break;
+        }
+        if (f == 3 && tid == 0) atomicMax(status, 1);
+        if (f == 2) {                                       // left to the IEEE instantiation of k_modec_persist
+            if (tid == 0) st.amb[atomicAdd(st.namb, 1)] = (int)i;
+        } else if (st.lnl_only == 2) {                      // the planes in their final form: every thread finishes the models it wrote itself
+            for (int j = tid; j < Mi; j += TPB) {
+                const int64_t k = i * M + j;
+                st.l[k] = chi2_logpdf<false>(0.5 * ((double)mc.nband - 1.0) - 1.0, st.c[k], st.lgtab[mc.nband], global_tabs());
+            }
+        } else if (SLDS && !st.lnl_only) {
+            for (int j = tid; j < Mi; j += TPB) st.s[i * M + j] = s_cur[j];
+        }
+        if (tid == 0 && f != 2) { atomicMax(st.last_iter, iters); if (st.niter) st.niter[i] = iters; }
         __syncthreads();
     }
 }

@@ -152,7 +152,8 @@ int  fz_fit_predict(fz_ctx* ctx, double* x, double* xe, double* xm, int64_t N,
 
 /* mode C (pdf.py:196-223) bookkeeping since the last fz_timing_reset, out4 = {objects whose stop decision fell within rounding
  * of ltol under the reciprocal-based solve and were re-run with IEEE divisions, iterations of the slowest object, 1 = one block
- * per object / 2 = state planes in HBM, threads per block of the former}; and the number of passes of the loop at pdf.py:199
+ * per object, one iteration per record read / 2 = state planes in HBM / 3 = one block per object, several iterations per record
+ * read (k_modec_rounds; objects it hands back to the IEEE kernel are counted in the first entry too), threads per block of 1 / 3}; and the number of passes of the loop at pdf.py:199
  * each of the first n objects of the LAST mode-C chunk took (int32, host) -- the reference does not return it, the tests compare
  * it with their restated loop. */
 int  fz_modec_info(fz_ctx* ctx, int64_t* out4);

@@ -1,8 +1,9 @@
 """Mode C (free scale WITH model errors, pdf.py:196-223) on every launch shape the library picks by model count:
-``k_modec_persist<1024,4>`` (M <= 4096), ``<768,14>`` (<= 10 752: the benchmarked 2e4 x 1e4 shape), ``<512,32>`` (<= 16 384)
+``k_modec_rounds<256 / 512 / 1024>`` (mask-free tame data, M <= 16 384: several iterations per record read, round 5),
+``k_modec_persist<1024,4>`` (M <= 4096), ``<768,14>`` (<= 10 752), ``<512,32>`` (<= 16 384: masked data, IEEE re-runs, ``FZ_MODEC_ROUNDS=0``)
 and the state-plane kernels ``k_modec_step / _check`` beyond -- against the oracle (whose iteration counter is pinned to the
 reference's by golden G2b), with per-model errors, with and without a masked band, at ltol 1e-4 and 1e-8; the switches
-``FZ_MODEC_IEEE`` / ``FZ_MODEC_PLANES`` / ``FZ_MODEC_FINAL`` / ``FZ_MODEC_BURST`` must leave iteration counts and ln-likes
+``FZ_MODEC_IEEE`` / ``FZ_MODEC_PLANES`` / ``FZ_MODEC_FINAL`` / ``FZ_MODEC_BURST`` / ``FZ_MODEC_ROUNDS`` must leave iteration counts and ln-likes
 unchanged; and an object whose max |dlnl| lands within rounding of ltol must take the IEEE re-run (fz_inst.hip, run_modec)."""
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ pytestmark = pytest.mark.gpu
 SDSS5 = np.array([0.873, 0.348, 0.418, 0.873, 3.476])
 KW = {'free_scale': True, 'ignore_model_err': False}
 SHAPES = {6000: (1, 768), 10000: (1, 768), 14000: (1, 512), 20000: (2, 0)}      # M -> (path, threads per block) of fz_modec_info
+ROUNDS = {6000: (3, 1024), 10000: (3, 1024), 14000: (3, 1024), 20000: (3, 512)}    # ... for mask-free data: k_modec_rounds (round 5)
 
 
 def problem(M, N, seed, masked=False, amps=(1.0, 0.5)):
@@ -59,7 +61,7 @@ def test_mode_c_every_launch_shape_against_the_oracle(M, masked, monkeypatch):
     for ltol in (1e-4, 1e-8):
         rows = [0, 9] if ltol == 1e-4 else [1]             # (object 9 is the slow one at M = 20 000: 521 / 805 passes)
         bf, niter, info = hip_fit(Y, Ye, Ym, X, Xe, Xm, ltol)
-        assert (info[2], info[3]) == SHAPES[M], info                  # the shape this test is about did run
+        assert (info[2], info[3]) == (SHAPES if masked else ROUNDS)[M], info   # the shape this test is about did run
         want = oracle_rows(Y, Ye, Ym, X, Xe, Xm, ltol, rows)
         for i, w in zip(rows, want):
             assert niter[i] == w[5], (M, ltol, i, niter[i], w[5])      # the reference's iteration count (oracle pinned by G2b)
@@ -72,7 +74,8 @@ def test_mode_c_every_launch_shape_against_the_oracle(M, masked, monkeypatch):
         assert info[1] == niter.max()
         # the switches: IEEE divisions throughout / the state-plane kernels (/ one host round trip per iteration) -- same iteration
         # count for EVERY object, ln-likes to 1e-10
-        for env in ({'FZ_MODEC_IEEE': '1'}, {'FZ_MODEC_PLANES': '1'}, {'FZ_MODEC_PLANES': '1', 'FZ_MODEC_IEEE': '1', 'FZ_MODEC_BURST': '1'}):
+        for env in ({'FZ_MODEC_IEEE': '1'}, {'FZ_MODEC_PLANES': '1'}, {'FZ_MODEC_PLANES': '1', 'FZ_MODEC_IEEE': '1', 'FZ_MODEC_BURST': '1'},
+                    {'FZ_MODEC_ROUNDS': '0'}):
             if ltol == 1e-8 and 'FZ_MODEC_BURST' in env:
                 continue
             with monkeypatch.context() as mp:
@@ -82,6 +85,8 @@ def test_mode_c_every_launch_shape_against_the_oracle(M, masked, monkeypatch):
             np.testing.assert_array_equal(niter2, niter)
             if 'FZ_MODEC_PLANES' in env:
                 assert info2[2] == 2
+            if 'FZ_MODEC_ROUNDS' in env or 'FZ_MODEC_IEEE' in env and 'FZ_MODEC_PLANES' not in env:
+                assert (info2[2], info2[3]) == SHAPES[M], info2          # one iteration per record read: k_modec_persist
             fin = np.isfinite(bf.fit_lnlike)
             np.testing.assert_array_equal(np.isfinite(bf2.fit_lnlike), fin)
             np.testing.assert_allclose(bf2.fit_lnlike[fin], bf.fit_lnlike[fin], rtol=1e-10, atol=1e-10)
@@ -94,7 +99,7 @@ def test_g2b_reference_rows_and_iteration_counts_at_ten_thousand_models():
     Y, Ye = g['Y'], g['Ye']
     for tname, ltol in (('t4', 1e-4), ('t8', 1e-8)):
         bf, niter, info = hip_fit(Y, Ye, np.ones_like(Y), g['X'], g['Xe'], np.ones((3, 5)), ltol)
-        assert info[2:] == (1, 768)
+        assert info[2:] == (3, 1024)
         for oi in range(3):
             k = 'o%d_%s' % (oi, tname)
             assert niter[oi] == int(g[k + '_niter'])
