@@ -658,9 +658,9 @@ def main():
             # the headline configuration has band-constant model errors (the easy case of mode A): the same workload (a) on the GENERAL
             # mode A kernels (per-model errors) and (b) with the free scale (mode B), two steps each, so that the driver's record holds
             # the cases real data run on.  (Every one of them is fp64 throughout since round 4: there is no separate all-fp64 line.)
-            def extra(Ye2, kw2, mode2, Ym2=None, dXm2=None):
+            def extra(Ye2, kw2, mode2, Ym2=None, dXm2=None, ze2=None):
                 eng.upload_models(Y, Ye2, Ym if Ym2 is None else Ym2)
-                eng.set_labels(z, ze, label_dict=pd)               # labels belong to the model set they were uploaded with
+                eng.set_labels(z, ze if ze2 is None else ze2, label_dict=pd)   # labels belong to the model set they were uploaded with
                 o2 = like_opts(kw2)
                 xm = dXm if dXm2 is None else dXm2
                 eng.fit_predict_prior(dX, dXe, xm, o2, ko, None, d_pdf, d_lm, d_le, n=N)
@@ -689,6 +689,11 @@ def main():
                                                    torch.from_numpy(Xm_c).to(dev)),
                                              note="mode A, per-model errors, 2 % of object bands and 2 % of model bands missing "
                                                   "(--model-err varying --mask-frac 0.02 --model-mask-frac 0.02)")
+            # ... and with per-model LABEL errors on top (gauss_kde_dict with ~30 kernel widths, pdf.py:599-620): what a training set is
+            out["roofline_catalogue_widths"] = dict(extra(Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape), {}, "A", Ym_c,
+                                                          torch.from_numpy(Xm_c).to(dev), np.random.RandomState(78).uniform(0.01, 0.1, size=ze.shape)),
+                                                    note="the catalogue line with per-model label errors "
+                                                         "(--model-err varying --mask-frac 0.02 --model-mask-frac 0.02 --label-err varying)")
         if "roofline_general" in out:
             # every BASELINE config the line's own workload does not cover, as sub-records (2-3 steps each; a failure is recorded, not raised)
             pp = _sub(lambda: sub_planes_predict(eng, dev, torch, pd))

@@ -350,6 +350,12 @@ extern "C" int fz_labels_upload_dict(fz_ctx* c, const int64_t* y_idx, const int6
             FZCHK(copy_in(c, c->d_mc_tag.p, tag.data(), Mp * 4)); FZCHK(copy_in(c, c->d_mc_perm.p, perm.data(), M * 4));
             FZCHK(copy_in(c, c->d_mc_width.p, rwidth.data(), C * 4)); FZCHK(copy_in(c, c->d_mc_off.p, roff.data(), C * 8));
             FZCHK(copy_in(c, c->d_mc_norm.p, ntab.data(), ntab.size() * 8));
+            {   // ... and its reciprocals (k_hist's class flush multiplies, fz_hist.h)
+                std::vector<double> rtab(ntab.size());
+                for (size_t q = 0; q < ntab.size(); ++q) rtab[q] = 1.0 / ntab[q];
+                FZCHK(c->d_mc_rnorm.ensure(rtab.size() * 8));
+                FZCHK(copy_in(c, c->d_mc_rnorm.p, rtab.data(), rtab.size() * 8));
+            }
             c->mc_ok = true; c->mc_gp = (int32_t)Gp; c->mc_w0 = (int32_t)W0;
         }
     }
@@ -1027,7 +1033,16 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
             // real-catalogue inputs (pdf.py:76-87 with models_mask / per-model models_err): masked MODELS in any mode, or objects with
             // unobserved bands against per-model errors -- the one-pass kernel on the segmented model layout (fz_hist.h, SEG); +1: the
             // form does not apply (too many mask patterns, a KDE form it does not take ...) and the chunk goes on as before
-            if ((var == VAR_MASKED || var == VAR_FAST) && c->BT == c->B && !c->prior.tab && (c->models_real_masked || (var == VAR_MASKED && mode == 0))) {
+            // ... with one dictionary kernel or many (per-model label errors: the layout is ordered by width class first).  Mask-free data
+            // with many widths keep k_fused's class-sorted stack (80 against 112 ms per 2.6e10 pairs: the per-class convolutions cost both
+            // kernels the same, and k_fused's weight-space loop has no group-by-group tiles at the class boundaries); FZ_HIST_SEG_MC=1
+            // sends them here too (tests).
+            const char* smc = getenv("FZ_HIST_SEG_MC");
+            const bool many_widths = c->label_mode == 1 && !c->single_cls;
+            const bool masks = c->models_real_masked || var == VAR_MASKED;
+            const bool seg_mc = many_widths && c->mc_ok && !(smc && atoi(smc) == 0) && (masks || (smc && atoi(smc) == 1));
+            if ((var == VAR_MASKED || var == VAR_FAST) && c->BT == c->B && !c->prior.tab &&
+                (many_widths ? seg_mc : (c->models_real_masked || (var == VAR_MASKED && mode == 0)))) {
                 const int r0 = run_fitpredict(c, mode, VAR_SEG, o->dim_prior, n, ko, d_lm, d_le, d_pdf);
                 if (r0 < 0) return r0;
                 done = (r0 == 0);

@@ -95,7 +95,7 @@ struct fz_ctx {
     DevBuf d_pos, d_cls, d_norm, d_normtab, d_ly, d_lstd, d_lo, d_hi, d_grid;
     // class-sorted copy of the fused kernel's model records + tables (many dictionary widths; fz_kernels.h, MC)
     bool mc_ok = false, mc_rec0_valid = false, mc_rec1_valid = false; int32_t mc_gp = 0, mc_w0 = 0;
-    DevBuf d_mc_tag, d_mc_perm, d_mc_width, d_mc_off, d_mc_norm, d_rec0p, d_rec1p;
+    DevBuf d_mc_tag, d_mc_perm, d_mc_width, d_mc_off, d_mc_norm, d_mc_rnorm, d_rec0p, d_rec1p;
     // segmented model layout of the one-pass kernel (k_hist<..., SEG>: masked models, per-model errors against masked objects):
     // records sorted by (dictionary class, mask pattern), segments padded to whole 64-model groups.  Built on first use from the host
     // copies below (fz_segments); seg_state: 0 not built, 1 built, -1 this model / label set does not take the form
@@ -125,7 +125,7 @@ struct fz_ctx {
 
     std::vector<DevBuf*> all_bufs() {
         std::vector<DevBuf*> v = {&d_y, &d_ye2, &d_ye, &d_rec0, &d_rec1, &d_ye2c, &d_mbits, &d_lgA, &d_lgB, &d_widths, &d_offsets, &d_kern, &d_pos,
-                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_rec0p, &d_rec1p, &d_seg_tag, &d_seg_perm, &d_seg_mask, &d_seg_rank, &d_seg_start, &d_seg_rec0, &d_seg_rec1, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
+                                  &d_cls, &d_norm, &d_normtab, &d_mc_tag, &d_mc_perm, &d_mc_width, &d_mc_off, &d_mc_norm, &d_mc_rnorm, &d_rec0p, &d_rec1p, &d_seg_tag, &d_seg_perm, &d_seg_mask, &d_seg_rank, &d_seg_start, &d_seg_rec0, &d_seg_rec1, &d_ly, &d_lstd, &d_lo, &d_hi, &d_grid, &d_sx, &d_sxe, &d_sxm, &d_rx, &d_rxe, &d_rxm, &d_ox,
                                   &d_ov, &d_obits, &d_oslv, &d_flags, &d_lmap, &d_levid, &d_pdfs, &d_pdfs2, &d_mcerr,
                                   &d_mcfn, &d_mcact, &d_mccnt, &d_mcniter, &d_cand, &d_kv, &d_omap, &d_redo, &d_sgrid, &d_sloss, &d_ptab, &d_prows, &d_lrec, &d_kgbox, &d_ktbox, &d_idxs, &d_trees, &d_q, &d_idx, &d_nbr, &d_nn, &d_tnorm, &d_kbmat, &d_kcen, &d_kpmax, &d_kperm, &d_ktab, &d_kqperm, &d_kqcnt};
         for (auto& b : d_pl) v.push_back(&b);

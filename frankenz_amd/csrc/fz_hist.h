@@ -386,6 +386,11 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             const int64_t os = i0 < N ? i0 : N - 1;
             const int64_t oi = omap ? (int64_t)omap[os] : os;
             src.park_obj(oi, obj0, lane);
+            if constexpr ((SRC::LMODE == 1 || SRC::LMODE == 2) && FZ_HIST_CHI2_2OP && !(SRC::LMODE == 2 && SRC::SAFE)) {
+                // the two-instruction chi2's units (s = sqrt(1 / var), xs = x s; below) once per object, not at every change of pattern
+                // (same lane wrote the entries: no fence needed)
+                if (lane < BT) { const double sv = sqrt(obj0[BT + lane]); obj0[BT + lane] = sv; obj0[lane] = obj0[lane] * sv; }
+            }
             obits = (uint32_t)__builtin_amdgcn_readfirstlane((int)src.ov.bits[oi]);
             oslv = uniform_d(src.ov.slv[oi]);
             const bool dp = src.lp.dim_prior != 0;
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     if constexpr (BT > 16) ob[o].x[b] = uniform_d(ob[o].x[b]);        // (32-band records: back to the scalar file, see above)
                 }
         }
+        [[maybe_unused]] const bool mcw = SEG && kv.seg_nrank > 1;      // many dictionary widths (class_flush below)
         HistState<TW> hs;
 #pragma unroll
         for (int o = 0; o < TW; ++o) {
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 // the list holds `cap` entries (the launcher sizes it well above what a well-fitted object needs, not at M): an
                 // object that would overflow it -- every model within the band of a poor best fit -- is handed to the exact sweep
                 if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
-                    if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                    if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                     hs.namb[o] += np;
                 } else hs.namb[o] = -1;                           // overflowed: nothing more is stored, the object goes to the sweep
             }
@@ -535,8 +541,8 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     if (hs.namb[o] >= 0 && hs.namb[o] + na + nb <= cap) {
                         const int pa = __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
                         const int pb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
-                        if (ama) { Cand e; e.lnl = ca; e.j = ta; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pa] = e; }
-                        if (amb) { Cand e; e.lnl = cb; e.j = tb2; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + na + pb] = e; }
+                        if (ama) { Cand e; e.lnl = ca; e.j = ta; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + pa] = e; }
+                        if (amb) { Cand e; e.lnl = cb; e.j = tb2; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + na + pb] = e; }
                         hs.namb[o] += na + nb;
                     } else hs.namb[o] = -1;
                 }
@@ -550,6 +556,49 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             const bool act = lane < n;
             settle(o, act, c2, tag, badc);
             hs.pend[o] = rest;
+        };
+        // SEG with many dictionary widths (kv.seg_nrank > 1; the segments are ordered by width class first): the histogram holds the
+        // weights of ONE class.  When the class of the model stream changes -- and at the finish -- the row is divided by the class's
+        // edge-truncated kernel mass per index (pdf.py:613-617; the reciprocals are tabulated), convolved with the class's kernel and
+        // ADDED to the object's PDF row in global memory (L2: 5.6 KB per object, touched ~30 times), then cleared.  The convolution is
+        // that of k_fused's class-sorted stack (pdf_stage_mc, fz_kernels.h): a lane owns 12 consecutive outputs, so one LDS read per
+        // lane and tap feeds 12 FMAs.  Class 0 comes first in the stream (ranks are dense and ascending): its flush WRITES the row.
+        [[maybe_unused]] auto class_flush = [&](int rk, double* row, double* gout) {
+            constexpr int NACC = 12;
+#if defined(FZ_DIAG_NOFLUSH)
+            return;
+#endif
+            const int G = (int)kv.G, Gp = kv.mc_gp, W0 = kv.mc_w0;
+            const int wc = kv.mc_width[rk], w2 = 2 * wc, sh = W0 - wc;
+            const double* nt = kv.mc_norm + (size_t)rk * Gp;                // 1 / mass
+            const double* kr = kv.kern + kv.mc_off[rk];
+            const double ka = (lane <= w2) ? kr[lane] : 0.0;                // w2 + 1 <= 127 taps in two registers across the wave
+            const double kb = (lane + 64 <= w2) ? kr[lane + 64] : 0.0;
+            for (int k = lane; k < Gp; k += 64) row[k] = row[k] * nt[k];
+            const int kal = __double2loint(ka), kah = __double2hiint(ka), kbl = __double2loint(kb), kbh = __double2hiint(kb);
+            const double* r0 = row + sh + NACC * min(lane, (G - 1) / NACC);  // lanes past G repeat the last lane's reads (unused sums); reads end < Gp + 12
+            double out[NACC], win[NACC];
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) { out[a] = 0.0; win[a] = r0[a]; }
+            for (int h = 0; h <= w2; h += NACC) {
+#pragma unroll
+                for (int u = 0; u < NACC; ++u) {
+                    if (h + u <= w2) {                                      // wave-uniform
+                        const int q = w2 - (h + u);
+                        const double tap = (q < 64) ? __hiloint2double(__builtin_amdgcn_readlane(kah, q), __builtin_amdgcn_readlane(kal, q))
+                                                    : __hiloint2double(__builtin_amdgcn_readlane(kbh, q - 64), __builtin_amdgcn_readlane(kbl, q - 64));
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) out[a] = fma(win[(a + u) % NACC], tap, out[a]);
+                        win[u] = r0[NACC + h + u];                          // the entry that left the window makes room for the next one
+                    }
+                }
+            }
+            for (int k = lane; k < Gp; k += 64) row[k] = 0.0;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int t = NACC * lane + a;
+                if (t < G) gout[t] = (rk == 0) ? out[a] : gout[t] + out[a];
+            }
         };
         // SEG: a group of another mask pattern begins: the pattern's power, normalisation, classifier constants and effective object
         // row.  The candidate buffer is EMPTY here -- the step before a change settles everything (its entries' power and factor
@@ -565,10 +614,14 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             ndcur = nd;
             K = uniform_d((double)wpr);
             rK = uniform_d(wpr > 0 ? 1.0 / (double)wpr : 1.0);
-            float tm_;
-            t_consts(K, hk23, T0c, tm_);
+            // (the classifier's constants and the mode value without a logarithm: K is a small integer here)
+            static constexpr double LOG2K[9] = {0.0, 0.0, 1.0, 1.5849625007211562, 2.0, 2.321928094887362, 2.584962500721156, 2.807354922057604, 3.0};
+            const double hk_ = 0.5 * K, l2k = LOG2K[wpr > 8 ? 8 : wpr];      // (wpr >= 0 here)
+            hk23 = (float)(hk_ / 8388608.0);
+            T0c = (float)(-hk_ * l2k + K * 0.7213475204444817 + hk_ * (-127.0 + 0.043));
             lgq = uniform_d(dp ? src.lp.lgtab[nd] : 0.5 * ((double)nd * FZ_LN2PI + oslv));
-            const double dl = uniform_d(lnl_c2(K)) - lref;             // the pattern's mode value against the reference: <= 0
+            // ln L at the mode chi2 = K: (K / 2) ln K - K / 2 - lgq
+            const double dl = uniform_d(fma(hk_, l2k * 0.6931471805599453, -hk_) - lgq) - lref;      // the pattern's mode value against the reference: <= 0
             fk = uniform_d(exp_neg(dl, tb));
             hk23 = uniform_f(hk23);
             T0c = uniform_f(T0c + (float)(dl * 1.4426950408889634));
@@ -583,7 +636,6 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
                 const bool on = (jb >> b) & 1u;
-                if constexpr (C2OP || C2OPB) { ob[0].v[b] = sqrt(ob[0].v[b]); ob[0].x[b] = ob[0].x[b] * ob[0].v[b]; }
                 // a band either side masks: inverse variance 0 (modes Ai / B: it adds exactly nothing to chi2, inter and shape); with
                 // per-model errors the VARIANCE term 2^(960 / BT) and flux 0 -- a masked MODEL band has y = ye^2 = 0 in the segment-ordered
                 // records, so d = 0 and the band adds exactly nothing; an unobserved OBJECT band adds y^2 / 2^192 (5 bands; 2^120 at 8)
@@ -712,7 +764,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                             const int np = __builtin_popcountll(mask);
                             if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
-                                if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = SEG ? ndcur : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
+                                if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                                 hs.namb[o] += np;
                             } else hs.namb[o] = -1;
                         }
@@ -832,7 +884,13 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             const int nxt = st + 1 < TILE / 64 ? (tags[(st + 1) * 64] >> 16) & 0x3fff : segcur;      // (wave-uniform read)
                             if (st >= 0) {
                                 const int sw = (__builtin_amdgcn_readfirstlane(ptag[0]) >> 16) & 0x7fff;
-                                if ((sw & 0x3fff) != segcur) seg_switch(sw);     // a few dozen times per pass; nothing waits in the buffer
+                                if ((sw & 0x3fff) != segcur) {                     // a few dozen times per pass; nothing waits in the buffer
+                                    if (mcw && segcur >= 0) {
+                                        const int rko = kv.seg_rank[segcur];
+                                        if (kv.seg_rank[sw & 0x3fff] != rko) class_flush(rko, rows, pdfs + (omap ? (int64_t)omap[i0] : i0) * kv.G);
+                                    }
+                                    seg_switch(sw);
+                                }
                             }
                             const bool flush = __builtin_amdgcn_readfirstlane(nxt) != segcur;        // (segcur: this group's pattern by now)
                             step_body(m, ptag, stc, t, tailc, std::true_type{}, flush);
@@ -906,6 +964,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 // the MODE leave the comfortable range (2^-400: every pair within the drop bar of it is still a normal number well above
                 // the exponential's clamp, and chi2 stays small enough -- < ~600 -- for the classifier's error bound): the exact ln-space sweep decides
                 const bool ok = (le - le == 0.0) && (lbest > -INFINITY) && (EXACT ? (wbest_run > 1e-24) : (tm >= -400.f)) && hs.namb[o] >= 0 && kok;
+                if constexpr (SEG) { if (mcw && segcur >= 0) class_flush(kv.seg_rank[segcur], row, pdfs + i * kv.G); }      // the last class
                 // the ambiguous band, by the reference's own rule (pdf.py:591) with the exact maximum and evidence
                 const int na = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                 if (na > 0) {
@@ -919,14 +978,31 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                         const Cand e1 = cb[in1 ? k : 0];
                         double l1, w1;
                         if constexpr (SEG) {
-                            // the entry's own N_dim (Cand::pad): power, normalisation, and its weight against the reference
-                            l1 = in1 ? seg_lnl(e1.lnl, e1.pad) : -INFINITY;
+                            // the entry's own N_dim (Cand::pad, low byte): power, normalisation, and its weight against the reference
+                            l1 = in1 ? seg_lnl(e1.lnl, e1.pad & 0xff) : -INFINITY;
                             w1 = exp_neg(l1 - lref, tb);
                         } else {
                             l1 = in1 ? lnl_c2(e1.lnl) : -INFINITY;
                             w1 = exactw_tab(e1.lnl, tb, std::false_type{});
                         }
                         const bool s1 = in1 && (exp_neg(l1 - le, tb) > thr);   // strict
+                        if constexpr (SEG) {
+                            if (mcw) {
+                                // many widths: the row is a PDF row by now (every class flushed, below): the entry's whole window goes in,
+                                // pdf.py:599-620 as written (a lane per entry; LDS atomics)
+                                if (s1) {
+                                    const int rk = e1.pad >> 8, wc = kv.mc_width[rk], p = e1.j - kv.mc_w0;
+                                    const double* kr = kv.kern + kv.mc_off[rk];
+                                    const double wn = w1 * kv.mc_norm[(size_t)rk * kv.mc_gp + e1.j];
+                                    const int G = (int)kv.G;
+                                    for (int h = 0; h <= 2 * wc; ++h) {
+                                        const int tq = p - wc + h;
+                                        if (tq >= 0 && tq < G) unsafeAtomicAdd(&row[tq], wn * kr[h]);
+                                    }
+                                }
+                                continue;
+                            }
+                        }
                         if (s1) unsafeAtomicAdd(&row[e1.j + w0], w1);
                     }
                 }
@@ -934,6 +1010,20 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                     if (lmap) lmap[i] = lbest;
                     if (levid) levid[i] = le;
                     if (!ok) redo[1 + atomicAdd(redo, 1)] = (int)i;
+                }
+                if constexpr (SEG) {
+                    if (mcw) {
+                        // the flushed classes (global row) + the ambiguous entries' windows (LDS row), normalised
+                        double* gout = pdfs + i * kv.G;
+                        const int G = (int)kv.G;
+                        if (!ok) { for (int tq = lane; tq < G; tq += 64) gout[tq] = NAN; continue; }
+                        double tot = 0.0;
+                        for (int tq = lane; tq < G; tq += 64) { const double vq = gout[tq] + row[tq]; row[tq] = vq; tot += vq; }
+                        tot = wave_sum(tot);
+                        const double sc = normalize ? 1.0 / tot : 1.0 / stot;
+                        for (int tq = lane; tq < G; tq += 64) gout[tq] = normalize ? row[tq] / tot : row[tq] * sc;
+                        continue;
+                    }
                 }
                 kde_finalize<true>(kv, row, ok, normalize, pdfs + i * kv.G, lane, ok ? 1.0 / stot : 1.0, true);
             }

@@ -357,7 +357,8 @@ double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t
 // the same likelihood when objects may have unobserved bands (the mask-free arithmetic of `src` does not know N_dim per object)
 // SEG (segmented model layout): `src` / `kv` / `M` are the segment-ordered records, their view and padded length; the sweep runs on
 // the caller's own records: `swsp`, `kv_sweep`, `M_sweep`
-template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), class SWS = SRC, bool SEG = false>
+// HOS: the sweep's KDE stage knows one dictionary kernel only (false: the general window stack -- many widths)
+template <class SRC, int TW, int NW, bool EXACT, bool OBJK = (SRC::NB > 8), class SWS = SRC, bool SEG = false, bool HOS = true>
 int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko,
                      double* lmap, double* levid, double* pdfs, const SWS* swsp = nullptr, const fz::KdeView* kv_sweep = nullptr,
                      int64_t M_sweep = 0) {
@@ -393,7 +394,7 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     } else if (fit < need) return 1;
     // the sweep over handed-back objects (exact ln-space body, candidate lists of M entries per wave): as many blocks as stay
     // resident and fit the workspace (with per-object band counts a few per cent of a chunk can land there), at least one per CU
-    auto sweep = fz::k_fused<SWS, 1, SW, false, true>;
+    auto sweep = fz::k_fused<SWS, 1, SW, false, HOS>;
     constexpr size_t TDB2 = (size_t)SWS::template tile_doubles<SWS::template tile_len<SW>()>();
     const size_t lds2 = ((size_t)((SW + 1) / 2) * kvs.acc_stride <= TDB2) ? 0 : (size_t)SW * kvs.acc_stride * 8;
     bool sweep_ok = false;
@@ -488,7 +489,10 @@ int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int
         fz::KdeView kv0;
         FZCHK(fz_kde_view(c, kv0));
         if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_SEG") && atoi(getenv("FZ_HIST_SEG")) == 0)) return 1;
-        if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv0.kmode != fz::KDE_HIST || !kv0.normtab) return 1;
+        // one dictionary kernel (histogram + one convolution), or many through the class-ordered segments (one convolution per class)
+        const bool mcw = kv0.kmode == fz::KDE_DICT && c->mc_ok && !(getenv("FZ_HIST_SEG_MC") && atoi(getenv("FZ_HIST_SEG_MC")) == 0);
+        if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31)) return 1;
+        if (!mcw && (kv0.kmode != fz::KDE_HIST || !kv0.normtab)) return 1;
         // without the dimensionality prior the ln-like of mode A carries sum_b ln(xe^2 + ye^2) of the PAIR (pdf.py:96-98): not a power-0 form
         if (!src.lp.dim_prior && SRC::LMODE == 0) return 1;
         if (SRC::LMODE == 0 && c->models_big) return 1;           // (fluxes beyond 1e9: the bound on an unobserved object band's term, fz_hist.h)
@@ -497,6 +501,12 @@ int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int
         fz::KdeView kv = kv0;
         kv.mc_tag = c->d_seg_tag.as<int32_t>(); kv.seg_mask = c->d_seg_mask.as<uint32_t>(); kv.seg_rank = c->d_seg_rank.as<int32_t>();
         kv.seg_start = c->d_seg_start.as<int32_t>(); kv.seg_n = c->seg_n; kv.seg_nrank = c->seg_nrank;
+        if (mcw != (c->seg_nrank > 1)) return 1;                  // (cannot happen: both say "more than one class present")
+        if (mcw) {
+            kv.mc_width = c->d_mc_width.as<int32_t>(); kv.mc_off = c->d_mc_off.as<int64_t>(); kv.mc_norm = c->d_mc_rnorm.as<double>();      // (reciprocals)
+            kv.mc_gp = c->mc_gp; kv.mc_w0 = c->mc_w0;
+            kv.acc_stride = c->mc_gp + 16;                       // + the tail pad the sliding window of the convolution reads into
+        }
         SRC s2 = src;
         s2.mv.rec0 = c->d_seg_rec0.as<double>(); s2.mv.rec1 = c->d_seg_rec1.as<double>();
         fz_exact_now() = false;
@@ -511,10 +521,17 @@ int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int
         }
         int r;
         constexpr int NWS = (SRC::LMODE == 0) ? FZ_HIST_SEG_NW0 : 16;      // waves per block (per-model errors: see FZ_HIST_SEG_NW0)
-        if (ex) r = fz_launch_hist_g<SRC, 1, NWS, true, true, SWS, true>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
+        // many widths: 12 waves per block (a histogram row of G + 2 W0 + 16 entries: 16 of them do not fit beside the tiles)
+        if (mcw) {
+            if (ex) r = fz_launch_hist_g<SRC, 1, 12, true, true, SWS, true, false>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
+            else if constexpr (SRC::LMODE != 2) r = fz_launch_hist_g<SRC, 1, 12, false, true, SWS, true, false>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
+            else r = 1;
+        }
+        else if (ex) r = fz_launch_hist_g<SRC, 1, NWS, true, true, SWS, true>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
         else if constexpr (SRC::LMODE != 2) r = fz_launch_hist_g<SRC, 1, NWS, false, true, SWS, true>(c, s2, kv, n, c->seg_Ms, ko, lmap, levid, pdfs, &sws, &kv0, M);
         else r = 1;
-        if (r <= 0) c->last_form = ex ? "k_hist<exact> (segmented models)" : "k_hist<screen> (segmented models)";
+        if (r <= 0) c->last_form = mcw ? (ex ? "k_hist<exact> (segmented models, many widths)" : "k_hist<screen> (segmented models, many widths)")
+                                       : (ex ? "k_hist<exact> (segmented models)" : "k_hist<screen> (segmented models)");
         return r;
     }
 }

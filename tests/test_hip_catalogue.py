@@ -166,3 +166,57 @@ def test_full_chip_launch_with_masked_models():
     close(p[pick][ok], rp[ok], rtol=1e-7, atol=1e-13); close(lm[pick][ok], rlm[ok], rtol=1e-9); close(le[pick][ok], rle[ok], **EVID64)
     fin = np.isfinite(p).all(axis=1)
     assert fin.mean() > 0.99 and np.abs(p[fin].sum(axis=1) - 1).max() < 1e-9
+
+
+@pytest.mark.parametrize('mode', ['A', 'Ai', 'B'])
+@pytest.mark.parametrize('masks', ['none', 'objects', 'models+objects'])
+def test_many_dictionary_widths_on_the_one_pass_kernel(mode, masks, monkeypatch):
+    """per-model label errors (gauss_kde_dict with many kernel widths, pdf.py:599-620) on the segmented kernel: the model stream is
+    ordered by width class, the histogram is convolved with its class's kernel and added to the PDF row at every change of class
+    (fz_hist.h, class_flush).  With and without masks; labels piled at both grid edges (truncated kernel masses), a class of one
+    model at either end of the width range; against the oracle, against the class-sorted stack of k_fused (FZ_HIST_SEG_MC=0), with
+    the ambiguous lists forced to overflow (the hand-back to the sweep), un-normalised, and in the form that weighs every pair."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    kw = MODES[mode]
+    rs = np.random.RandomState(1200 + len(mode) + len(masks))
+    M, N, B = 12000 if masks == 'models+objects' else 3300, 420, 5
+    Y, Ye, Ym, X, Xe, Xm, z, ze = catalogue(rs, M, N, B, 'varying', 0.0, 0.1 if masks != 'none' else 0.0)
+    if masks == 'models+objects':                                  # four mask patterns x ~30 classes: 120 segments (every pattern of every class is
+        Ym[rs.uniform(size=M) < 0.15, 1] = 0.0                     # padded to whole 64-model groups; the layout is declined when pads would dominate)
+        Ym[rs.uniform(size=M) < 0.10, 3] = 0.0
+    z = np.clip(rs.uniform(-0.3, 7.3, M), 0.0, 7.0)
+    ze = rs.uniform(0.01, 0.12, M)                                 # ~28 classes, half-widths 5..60
+    ze[7] = 0.125; ze[8] = 0.006
+    X[Xm == 0] = 1e6; Y[Ym == 0] = -3.0
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda **kk: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=kw, return_gof=True, save_fits=False,
+                                      verbose=False, **kk)
+    want = 'k_hist<exact> (segmented models, many widths)' if mode == 'B' else 'k_hist<screen> (segmented models, many widths)'
+    with np.errstate(all='ignore'):
+        if masks == 'none':
+            monkeypatch.setenv('FZ_HIST_SEG_MC', '1')              # (mask-free data keep k_fused's class-sorted stack by default: faster there)
+        p0, (lm0, le0) = run()
+        assert get_engine().last_form() == want
+        monkeypatch.setenv('FZ_HIST_SEG_MC', '0')
+        p1, (lm1, le1) = run()
+        assert 'many widths' not in get_engine().last_form()
+        monkeypatch.delenv('FZ_HIST_SEG_MC')
+        if masks == 'none':
+            monkeypatch.setenv('FZ_HIST_SEG_MC', '1')
+        monkeypatch.setenv('FZ_HIST_AMBCAP', '2')                  # nearly every object overflows its list: the exact sweep redoes it
+        p2, (lm2, le2) = run()
+        monkeypatch.delenv('FZ_HIST_AMBCAP')
+        monkeypatch.setenv('FZ_NOLIST', '1')
+        p3, (lm3, le3) = run()
+        assert get_engine().last_form() == 'k_hist<exact> (segmented models, many widths)'
+        monkeypatch.delenv('FZ_NOLIST')
+        rp, rlm, rle = fo.bruteforce_fit_predict(X.copy(), Xe.copy(), Xm.copy(), Y, Ye, Ym, z, ze, label_dict=od, **kw)
+    ok = ~undefined_rows(mode, Xm, Ym) & np.isfinite(rp).all(axis=1)
+    assert ok.mean() > 0.8
+    for p, lm, le in ((p0, lm0, le0), (p2, lm2, le2), (p3, lm3, le3)):
+        close(p[ok], rp[ok], rtol=1e-7, atol=1e-13); close(lm[ok], rlm[ok], rtol=1e-9); close(le[ok], rle[ok], **EVID64)
+        np.testing.assert_allclose(p[ok].sum(axis=1), 1.0, rtol=1e-12)
+    fin = np.isfinite(p1).all(axis=1) & ok
+    close(p0[fin], p1[fin], rtol=1e-7, atol=1e-13); close(le0[fin], le1[fin], **EVID)
