@@ -59,6 +59,7 @@ ABI = {
     "fz_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "fz_ctx_destroy": (None, [_P]),
     "fz_sync": (C.c_int, [_P]),
+    "fz_debug_opts": (C.c_int, [C.c_char_p]),
     "fz_timing_reset": (C.c_int, [_P]),
     "fz_timing_get": (C.c_int, [_P, C.POINTER(Timing)]),
     "fz_last_form": (C.c_char_p, [_P]),
@@ -118,8 +119,40 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Switched(lib)
+    return _lib
+
+
+class _Switched(object):
+    """The loaded library.  Its test / tuning switches ("FZ_..." names) are not read from the
+    environment by the C side: this layer hands the process's ``FZ_*`` variables over through the ONE entry point
+    ``fz_debug_opts`` whenever they have changed since the last call, so that ``FZ_HIST=0 python bench.py`` and a
+    test's ``monkeypatch.setenv`` keep working."""
+    _SKIP = ("fz_last_error", "fz_debug_opts", "fz_host_alloc", "fz_host_free")
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_raw", lib)
+        object.__setattr__(self, "_sent", None)
+        object.__setattr__(self, "_fn", {})
+
+    def _sync(self):
+        spec = ";".join("%s=%s" % kv for kv in sorted(os.environ.items()) if kv[0].startswith("FZ_"))
+        if spec != self._sent:
+            self._raw.fz_debug_opts(spec.encode())
+            object.__setattr__(self, "_sent", spec)
+
+    def __getattr__(self, name):
+        fn = self._fn.get(name)
+        if fn is None:
+            raw = getattr(self._raw, name)
+            if name in self._SKIP:
+                fn = raw
+            else:
+                def fn(*a, _raw=raw, _sync=self._sync):
+                    _sync()
+                    return _raw(*a)
+            self._fn[name] = fn
+        return fn
 
 
 # error code -> Python exception, mirroring what the reference raises

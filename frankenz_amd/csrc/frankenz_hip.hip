@@ -2,6 +2,7 @@
 // This translation unit: context, uploads, object preparation, the ABI entry points
 // and the kernels that do not depend on the band count.  The photometric kernels
 // are instantiated per band count in fz_inst.hip.
+#include <mutex>
 #include "fz_ctx.h"
 #include "fz_kernels.h"
 #include "fz_cdf.h"
@@ -16,6 +17,32 @@ using namespace fz;
 
 std::string& fz_err_slot() { static thread_local std::string e; return e; }
 extern "C" const char* fz_last_error(void) { return fz_err_slot().c_str(); }
+
+// ---- test / tuning switches: one call sets them, nothing reads the environment ----
+namespace {
+struct DbgOpts { std::mutex mu; std::vector<std::pair<std::string, std::string>> kv; };
+DbgOpts& dbg_opts() { static DbgOpts d; return d; }
+}
+const char* fz_dbg(const char* name) {
+    DbgOpts& d = dbg_opts();
+    std::lock_guard<std::mutex> lk(d.mu);
+    for (auto& e : d.kv) if (e.first == name) return e.second.c_str();      // (stable until the next fz_debug_opts)
+    return nullptr;
+}
+extern "C" int fz_debug_opts(const char* spec) {
+    DbgOpts& d = dbg_opts();
+    std::lock_guard<std::mutex> lk(d.mu);
+    d.kv.clear();
+    if (!spec) return 0;
+    const char* p = spec;
+    while (*p) {
+        const char* e = p; while (*e && *e != ';') ++e;
+        const char* q = p; while (q < e && *q != '=') ++q;
+        if (q > p) d.kv.emplace_back(std::string(p, q), q < e ? std::string(q + 1, e) : std::string());
+        p = *e ? e + 1 : e;
+    }
+    return 0;
+}
 extern "C" const char* fz_last_form(fz_ctx* c) { return c ? c->last_form.c_str() : ""; }
 
 extern "C" int fz_device_count(void) {
@@ -203,7 +230,7 @@ extern "C" int fz_models_upload(fz_ctx* c, const double* y, const double* ye, co
     // band-constant model errors (zeros for a template grid, a common floor, the SURVEY 8d
     // configurations): xe^2 + ye^2 does not depend on the model, so it is formed once per object
     // and mode A runs on the kernels of mode Ai (see obj_vmode); FZ_NO_ERRCONST=1 disables this
-    c->models_err_const = !(fl & 8) && !getenv("FZ_NO_ERRCONST");
+    c->models_err_const = !(fl & 8) && !fz_dbg("FZ_NO_ERRCONST");
     {
         std::vector<double> e0(B), e2(BT, 0.0);
         FZCHK(copy_out(c, e0.data(), c->d_rxe.p, (size_t)B * 8));
@@ -953,14 +980,14 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
     const bool cdf = !ko->use_wt_thresh;          // reference CDF rule: materialise the chunk's ln-like rows
     PriorBind pb; PriorGuard guard{c};
     FZCHK(prior_begin(c, pr, N, M, pb));
-    int64_t nc = std::min<int64_t>(N, getenv("FZ_CHUNK") ? atoll(getenv("FZ_CHUNK")) : (1 << 20));   // the fused kernel's workspace does not grow with the chunk
+    int64_t nc = std::min<int64_t>(N, fz_dbg("FZ_CHUNK") ? atoll(fz_dbg("FZ_CHUNK")) : (1 << 20));   // the fused kernel's workspace does not grow with the chunk
     const int64_t per_obj = M * 8 * (mode == 3 ? 4 : (cdf ? 1 : 0)) + pb.chunk_bytes_per_obj;
     if (per_obj) nc = std::min<int64_t>(nc, std::max<int64_t>(1, c->ws_limit / per_obj));
     // Host PDFs are the bulk of the PCIe traffic of the drop-in call (5.6 GB at 1e6 objects, longer
     // than the kernel).  Pipeline: chunks of 2^17 objects, two device staging buffers, chunk k's rows
     // leave on a second stream while chunk k+1 is being computed; kernel timing is deferred so that
     // the host does not wait on a kernel before it has queued the previous chunk's copy.
-    const bool pipe = !pdf_dev && mode != 3 && !cdf && N >= (3 << 17) && !getenv("FZ_NO_PIPELINE");
+    const bool pipe = !pdf_dev && mode != 3 && !cdf && N >= (3 << 17) && !fz_dbg("FZ_NO_PIPELINE");
     if (pipe) nc = std::min<int64_t>(nc, 1 << 17);               // (the last chunk's rows leave with nothing to hide behind: keep it small)
     struct PipeGuard {
         fz_ctx* c; bool on;
@@ -1037,7 +1064,7 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
             // with many widths keep k_fused's class-sorted stack (80 against 112 ms per 2.6e10 pairs: the per-class convolutions cost both
             // kernels the same, and k_fused's weight-space loop has no group-by-group tiles at the class boundaries); FZ_HIST_SEG_MC=1
             // sends them here too (tests).
-            const char* smc = getenv("FZ_HIST_SEG_MC");
+            const char* smc = fz_dbg("FZ_HIST_SEG_MC");
             const bool many_widths = c->label_mode == 1 && !c->single_cls;
             const bool masks = c->models_real_masked || var == VAR_MASKED;
             const bool seg_mc = many_widths && c->mc_ok && !(smc && atoi(smc) == 0) && (masks || (smc && atoi(smc) == 1));
@@ -1054,7 +1081,7 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
                 if (r0 < 0) return r0;
                 done = (r0 == 0);
             }
-            if (!done && var == VAR_MASKED && !c->models_real_masked && (c->BT == c->B || c->BT > 8) && n >= 4096 && !getenv("FZ_NO_SPLIT")) {
+            if (!done && var == VAR_MASKED && !c->models_real_masked && (c->BT == c->B || c->BT > 8) && n >= 4096 && !fz_dbg("FZ_NO_SPLIT")) {
                 FZCHK(c->d_omap.ensure((size_t)n * 8 + 64));
                 int* fast = c->d_omap.as<int>(); int* slow = fast + n; int* counts = slow + n;
                 HIPCHK(hipMemsetAsync(counts, 0, 8, c->stream));

@@ -51,6 +51,10 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Test / tuning switches ("FZ_..." names): set by ONE call, fz_debug_opts (include/frankenz_hip.h) -- the library does not read the
+// environment.  nullptr when the switch is not set (the meaning getenv had for the code that consults it).
+const char* fz_dbg(const char* name);
+
 struct fz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -51,7 +51,7 @@ int FZ_NAME(fz_planes_bt)(fz_ctx* c, int mode, int var, int dim_prior, int64_t n
     const int64_t M = c->M;
     // two adjacent models per thread (16-B stores) when every plane row starts 16-B aligned
     const uintptr_t al = (uintptr_t)lnl | (uintptr_t)chi2 | (uintptr_t)ndim | (uintptr_t)scale | (uintptr_t)serr;
-    const char* e_mpt = getenv("FZ_PLANES_MPT");
+    const char* e_mpt = fz_dbg("FZ_PLANES_MPT");
     const int MPT = (M % 2 == 0 && (al & 15) == 0 && !(e_mpt && atoi(e_mpt) == 1)) ? 2 : 1;
     const int64_t mblocks = (M + 256 * MPT - 1) / (256 * MPT);
     // objects per block: 256 when the grid still holds >= 4 blocks per CU (+11 % at 1e5 x 1e4), else 16
@@ -177,14 +177,14 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     HIPCHK(hipMemsetAsync(st.err, 0, 2 * n * 8, c->stream));
     HIPCHK(hipMemsetAsync(st.firstnan, 0, n * 4, c->stream));
     // the reciprocal-based solve for mask-free tame data (fz_modec.h); FZ_MODEC_IEEE=1 keeps the IEEE divisions throughout
-    const bool fast = !MASKED && tame && !getenv("FZ_MODEC_IEEE");
+    const bool fast = !MASKED && tame && !fz_dbg("FZ_MODEC_IEEE");
     st.amb = fast ? c->d_mcact.as<int>() + 2 * n : nullptr; st.namb = counts + 3; st.ambflag = fast ? c->d_mcact.as<int>() + 3 * n : nullptr;
     if (fast) HIPCHK(hipMemsetAsync(st.ambflag, 0, n * 4, c->stream));
     ModeC<BT, MASKED> mc; mc.mv = model_view(c); mc.ov = obj_view(c); mc.nband = c->B; mc.sub = sub;
     const int64_t tiles = (M + 255) / 256;
     if (n * tiles > 0x7fffffffLL) return fail(-1, "mode C chunk too large");
     const int max_iter = o->max_iter > 0 ? o->max_iter : 10000;
-    const int burst = getenv("FZ_MODEC_BURST") ? std::max(1, atoi(getenv("FZ_MODEC_BURST"))) : 8;
+    const int burst = fz_dbg("FZ_MODEC_BURST") ? std::max(1, atoi(fz_dbg("FZ_MODEC_BURST"))) : 8;
     Timer t(c, &c->tm.ms_modec, &c->tm.n_modec);
     int it_max = 0;
     const int want_lnl_only = c->mc_lnl_only;
@@ -224,8 +224,8 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     // beyond FZ_MCP_MAXM models (mask-free tame data): k_modec_rounds with the scales in the scale plane instead of LDS -- no limit on M;
     // objects it hands back are redone by the state-plane kernels with IEEE divisions
     {
-        const char* ev = getenv("FZ_MODEC_ROUNDS");
-        if (fast && M > FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES") && !(ev && ev[0] == '0')) {
+        const char* ev = fz_dbg("FZ_MODEC_ROUNDS");
+        if (fast && M > FZ_MCP_MAXM && !fz_dbg("FZ_MODEC_PLANES") && !(ev && ev[0] == '0')) {
             using MCT = ModeC<BT, MASKED>;
             if constexpr (!MASKED) {
                 HIPCHK(hipMemsetAsync(counts + 4, 0, 4, c->stream));
@@ -257,8 +257,8 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
             }
         }
     }
-    if (M <= FZ_MCP_MAXM && !getenv("FZ_MODEC_PLANES")) {
-        if (want_lnl_only && !sub.nbr && !getenv("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
+    if (M <= FZ_MCP_MAXM && !fz_dbg("FZ_MODEC_PLANES")) {
+        if (want_lnl_only && !sub.nbr && !fz_dbg("FZ_MODEC_FINAL")) { st.lnl_only = o->dim_prior ? 2 : 1; c->mc_lnl_only = 1; }
         // the whole fixed point of an object inside one block (fz_modec.h, k_modec_persist): no state planes through HBM
         auto launch = [&](auto kern, int T, size_t lds, const int* list, int64_t nobj) -> int {
             HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -275,14 +275,10 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
             const size_t lds = (size_t)M * 8;                    // the previous scale of every model
             if constexpr (F && !MASKED) {
                 // several iterations per record read (k_modec_rounds); FZ_MODEC_ROUNDS=0: one iteration per read (k_modec_persist)
-                const char* ev = getenv("FZ_MODEC_ROUNDS");
+                const char* ev = fz_dbg("FZ_MODEC_ROUNDS");
                 if (!(ev && ev[0] == '0')) {
                     c->mc_info[2] = 3;
                     HIPCHK(hipMemsetAsync(counts + 4, 0, 4, c->stream));
-                    const int shape = getenv("FZ_MCR_SHAPE") ? atoi(getenv("FZ_MCR_SHAPE")) : 0;
-                    if (shape == 1) { c->mc_info[3] = 256; return launch(k_modec_rounds<MCT, 256, false>, 256, 0, list, nobj); }
-                    if (shape == 2) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, false>, 512, 0, list, nobj); }
-                    if (shape == 3) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, true>, 512, lds, list, nobj); }
                     if (M <= 1024) { c->mc_info[3] = 256; return launch(k_modec_rounds<MCT, 256, true>, 256, lds, list, nobj); }
                     if (M <= 4096) { c->mc_info[3] = 512; return launch(k_modec_rounds<MCT, 512, true>, 512, lds, list, nobj); }
                     c->mc_info[3] = 1024;
@@ -302,14 +298,11 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
         HIPCHK(hipMemcpyAsync(res, counts + 1, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const int namb = res[2];
-        const bool trace = getenv("FZ_MODEC_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "mode C: first launch done: status %d, slowest object %d iterations, %d objects handed to the IEEE kernel\n", res[0], res[1], res[2]);
         if (fast && namb > 0 && !res[0]) {
             FZCHK(run(std::false_type{}, st.amb, namb));
             HIPCHK(hipMemcpyAsync(res, counts + 1, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             res[2] = namb;
-            if (trace) fprintf(stderr, "mode C: IEEE launch done: status %d, slowest object %d iterations\n", res[0], res[1]);
         }
         HIPCHK(hipGetLastError());
         if (res[0]) return fail(-7, "mode C (free_scale with model errors): objects not converged after %d iterations "
@@ -354,7 +347,7 @@ int FZ_NAME(fz_modec_bt)(fz_ctx* c, int var, int64_t n, const fz_like_opts* o, c
 // ---------------------------------------------------------------------------
 int FZ_NAME(fz_knnquery_bt)(fz_ctx* c, const double* q, int64_t n, int k, double bound2, int64_t* idx, int pnorm) {
     constexpr int TQ = (FZ_BT <= 5) ? 4 : (FZ_BT <= 8 ? 2 : 1);     // queries per wave (register budget)
-    const bool screen = pnorm == 2 && !getenv("FZ_KNN_FP64");
+    const bool screen = pnorm == 2 && !fz_dbg("FZ_KNN_FP64");
     const int64_t per = (int64_t)(screen ? (TQ >= 2 ? TQ : 2) : TQ) * 4;
     dim3 grid((unsigned)((n + per - 1) / per), (unsigned)c->knn_K);
     Timer t(c, &c->tm.ms_knn, &c->tm.n_knn);

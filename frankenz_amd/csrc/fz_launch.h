@@ -24,11 +24,11 @@ inline int fz_kde_view(fz_ctx* c, fz::KdeView& kv) {
     } else {
         kv.ly = c->d_ly.as<double>(); kv.lstd = c->d_lstd.as<double>(); kv.lo = c->d_lo.as<int32_t>(); kv.hi = c->d_hi.as<int32_t>();
         kv.grid = c->d_grid.as<double>();
-        kv.gstep = getenv("FZ_GRID_RECUR") && atoi(getenv("FZ_GRID_RECUR")) == 0 ? 0.0 : c->grid_step;
+        kv.gstep = fz_dbg("FZ_GRID_RECUR") && atoi(fz_dbg("FZ_GRID_RECUR")) == 0 ? 0.0 : c->grid_step;
         kv.lrec = c->d_lrec.as<double>();
         kv.kmode = KDE_GRID; kv.acc_stride = (int)c->G;
     }
-    kv.lane_window = getenv("FZ_LANE_WINDOW") ? atoi(getenv("FZ_LANE_WINDOW")) : FZ_LANE_WINDOW;
+    kv.lane_window = fz_dbg("FZ_LANE_WINDOW") ? atoi(fz_dbg("FZ_LANE_WINDOW")) : FZ_LANE_WINDOW;
     if ((size_t)kv.acc_stride * 8 > 160 * 1024)
         return fail(-5, "PDF grid of %lld points needs %zu B of LDS per object (> 160 KiB)", (long long)kv.G,
                     (size_t)kv.acc_stride * 8);
@@ -142,19 +142,19 @@ inline int fz_launch_plane_predict(fz_ctx* c, const double* plane, int64_t n, in
     const bool vec2 = (M % 2 == 0) && (((uintptr_t)plane & 15) == 0);
     const bool ho = kv.kmode == KDE_HIST;              // single-kernel label sets: the instantiation without the window code
     // the weights below wt_thresh of the best in fp32 unless the caller asked for the all-fp64 logsumexp (or thresholds nothing)
-    const bool x32 = !ko->exact_evidence && !c->exact_evidence && !getenv("FZ_EXACT_EVIDENCE") && ko->wt_thresh > 0.0;
+    const bool x32 = !ko->exact_evidence && !c->exact_evidence && !fz_dbg("FZ_EXACT_EVIDENCE") && ko->wt_thresh > 0.0;
     auto kern = x32 ? (vec2 ? (ho ? k_plane_fused<NW, 2, true, true> : k_plane_fused<NW, 2, false, true>)
                             : (ho ? k_plane_fused<NW, 1, true, true> : k_plane_fused<NW, 1, false, true>))
                     : (vec2 ? (ho ? k_plane_fused<NW, 2, true, false> : k_plane_fused<NW, 2, false, false>)
                             : (ho ? k_plane_fused<NW, 1, true, false> : k_plane_fused<NW, 1, false, false>));
     // rows that fit one block's registers: exact maximum first, then fp64 weights straight into the LDS histogram (fz_plane.h)
-    if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && vec2 && ho && kv.normtab && ko->wt_thresh >= 0.0 &&
-        (!getenv("FZ_PLANE_ROWS") || atoi(getenv("FZ_PLANE_ROWS")) != 0)) {
+    if (!linear && !c->force_twopass && !fz_dbg("FZ_PLANE_TWOPASS") && vec2 && ho && kv.normtab && ko->wt_thresh >= 0.0 &&
+        (!fz_dbg("FZ_PLANE_ROWS") || atoi(fz_dbg("FZ_PLANE_ROWS")) != 0)) {
         const int r = fz_launch_plane_rows(c, plane, kv, n, M, ko, lmap, levid, pdfs);
         if (r <= 0) return r;
     }
     int64_t blocks = 0;
-    if (!linear && !c->force_twopass && !getenv("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
+    if (!linear && !c->force_twopass && !fz_dbg("FZ_PLANE_TWOPASS") && lds <= 160 * 1024 && M < ((int64_t)1 << 31)) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int bpc = 1;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, lds));
@@ -213,7 +213,7 @@ int fz_launch_fused_wm(fz_ctx* c, const SRC& src_in, const fz::KdeView& kv_in, i
     // present (fz_kernels.h, pdf_stage_mc); FZ_NO_MC=1 keeps the per-model window adds
     bool mc = false;
     if constexpr (WM && (NW == 12 || NW == 4)) {      // (2,16) spills inside the model loop with this PDF stage: the dispatcher sends it to (2,12)
-        if (kv.kmode == fz::KDE_DICT && c->mc_ok && !getenv("FZ_NO_MC")) {
+        if (kv.kmode == fz::KDE_DICT && c->mc_ok && !fz_dbg("FZ_NO_MC")) {
             FZCHK(fz_mc_records(c, SRC::LMODE == 0));
             src.mv.rec0 = c->d_rec0p.as<double>(); src.mv.rec1 = c->d_rec1p.as<double>();
             kv.mc_tag = c->d_mc_tag.as<int32_t>(); kv.mc_width = c->d_mc_width.as<int32_t>(); kv.mc_off = c->d_mc_off.as<int64_t>();
@@ -304,7 +304,7 @@ constexpr bool fz_has_wspace() {
 inline bool& fz_exact_now() { static thread_local bool v = false; return v; }
 template <class SRC>
 bool fz_use_wspace(const SRC& src) {
-    if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !getenv("FZ_NO_WSPACE") && !fz_exact_now();
+    if constexpr (fz_has_wspace<SRC>()) return src.lp.dim_prior && !fz_dbg("FZ_NO_WSPACE") && !fz_exact_now();
     return false;
 }
 template <class SRC, int TW, int NW>
@@ -323,7 +323,7 @@ template <class SRC>
 double fz_nolist_probe(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, int64_t M, const fz_kde_opts* ko) {
     if constexpr (!fz_has_wspace<SRC>()) return -1.0;
     else {
-        if (!src.lp.dim_prior || getenv("FZ_NO_WSPACE") || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return -1.0;
+        if (!src.lp.dim_prior || fz_dbg("FZ_NO_WSPACE") || kv.kmode != fz::KDE_HIST || !kv.normtab || !(ko->wt_thresh > 0.0)) return -1.0;
         const int S = 256;
         const double denom = (double)S * (double)((M + 255) / 256) * 64.0;
         if (!c->h_probe) {
@@ -382,7 +382,7 @@ int fz_launch_hist_g(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n
     // M up to 131 072 models (can never overflow), M / 8 beyond (an object that overflows is re-run by the exact sweep): a
     // 1e6-model set then keeps the whole chip busy inside the workspace budget
     int64_t acap = (M <= 131072) ? M : std::max<int64_t>(131072, M / 8);
-    if (const char* e = getenv("FZ_HIST_AMBCAP")) acap = std::max<int64_t>(1, atoll(e));      // (tests: forces the overflow hand-back)
+    if (const char* e = fz_dbg("FZ_HIST_AMBCAP")) acap = std::max<int64_t>(1, atoll(e));      // (tests: forces the overflow hand-back)
     const size_t per_wave = (size_t)TW * acap * sizeof(fz::Cand);
     const int64_t fit = (int64_t)(c->ws_limit / (per_wave * NW));
     int64_t blocks = need;
@@ -444,7 +444,7 @@ int fz_launch_hist(fz_ctx* c, const SRC& src, const fz::KdeView& kv, int64_t n, 
         const bool ex = exact || SRC::LMODE == 2;
         if constexpr (SRC::NB > 8) {
             // wide records: one object per wave, eight waves per block (up to 256 registers per lane)
-            if (getenv("FZ_HIST_WIDE") && atoi(getenv("FZ_HIST_WIDE")) == 0) return 1;      // (tests: the masked kernels of round 2)
+            if (fz_dbg("FZ_HIST_WIDE") && atoi(fz_dbg("FZ_HIST_WIDE")) == 0) return 1;      // (tests: the masked kernels of round 2)
             if (ex) return fz_launch_hist_g<SRC, 1, 8, true>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             return fz_launch_hist_g<SRC, 1, 8, false>(c, src, kv, n, M, ko, lmap, levid, pdfs);
         } else {
@@ -464,10 +464,10 @@ int fz_launch_hist_objmask(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n,
     else {
         fz::KdeView kv;
         FZCHK(fz_kde_view(c, kv));
-        if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_OBJMASK") && atoi(getenv("FZ_HIST_OBJMASK")) == 0)) return 1;
+        if (c->force_twopass || (fz_dbg("FZ_HIST") && atoi(fz_dbg("FZ_HIST")) == 0) || (fz_dbg("FZ_HIST_OBJMASK") && atoi(fz_dbg("FZ_HIST_OBJMASK")) == 0)) return 1;
         // (every form of k_hist forms and sums its weights in fp64: a request for the exact evidence needs no other kernel)
         if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31) || kv.kmode != fz::KDE_HIST || !kv.normtab) return 1;
-        if (!src.lp.dim_prior && getenv("FZ_HIST_NODIMPRIOR") && atoi(getenv("FZ_HIST_NODIMPRIOR")) == 0) return 1;
+        if (!src.lp.dim_prior && fz_dbg("FZ_HIST_NODIMPRIOR") && atoi(fz_dbg("FZ_HIST_NODIMPRIOR")) == 0) return 1;
         fz_exact_now() = false;
         constexpr int NWH = SRC::NB > 8 ? 8 : 16;
         int r;
@@ -488,9 +488,9 @@ int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int
     else {
         fz::KdeView kv0;
         FZCHK(fz_kde_view(c, kv0));
-        if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0) || (getenv("FZ_HIST_SEG") && atoi(getenv("FZ_HIST_SEG")) == 0)) return 1;
+        if (c->force_twopass || (fz_dbg("FZ_HIST") && atoi(fz_dbg("FZ_HIST")) == 0) || (fz_dbg("FZ_HIST_SEG") && atoi(fz_dbg("FZ_HIST_SEG")) == 0)) return 1;
         // one dictionary kernel (histogram + one convolution), or many through the class-ordered segments (one convolution per class)
-        const bool mcw = kv0.kmode == fz::KDE_DICT && c->mc_ok && !(getenv("FZ_HIST_SEG_MC") && atoi(getenv("FZ_HIST_SEG_MC")) == 0);
+        const bool mcw = kv0.kmode == fz::KDE_DICT && c->mc_ok && !(fz_dbg("FZ_HIST_SEG_MC") && atoi(fz_dbg("FZ_HIST_SEG_MC")) == 0);
         if (!(ko->wt_thresh > 0.0) || M >= ((int64_t)1 << 31)) return 1;
         if (!mcw && (kv0.kmode != fz::KDE_HIST || !kv0.normtab)) return 1;
         // without the dimensionality prior the ln-like of mode A carries sum_b ln(xe^2 + ye^2) of the PAIR (pdf.py:96-98): not a power-0 form
@@ -512,9 +512,9 @@ int fz_launch_hist_seg(fz_ctx* c, const SRC& src, const SWS& sws, int64_t n, int
         fz_exact_now() = false;
         // direct form: the free scale always (fz_hist.h); broad likelihoods by the sampled share of pairs within the threshold (the
         // sample's mask-free arithmetic is an estimate here, which is all the choice needs); FZ_NOLIST=1 / 0 forces / forbids
-        bool ex = SRC::LMODE == 2 || (getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0);
+        bool ex = SRC::LMODE == 2 || (fz_dbg("FZ_EXACT_EVIDENCE") && atoi(fz_dbg("FZ_EXACT_EVIDENCE")) != 0);
         if (!ex) {
-            const char* e = getenv("FZ_NOLIST");
+            const char* e = fz_dbg("FZ_NOLIST");
             const int want = e ? atoi(e) : -1;
             if (want < 0 && n >= 16384) ex = fz_nolist_probe<SRC>(c, src, kv0, n, M, ko) > 0.12;
             else ex = want == 1;
@@ -541,9 +541,9 @@ template <class SRC>
 int fz_launch_hist_only(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const fz_kde_opts* ko, double* lmap, double* levid, double* pdfs) {
     fz::KdeView kv;
     FZCHK(fz_kde_view(c, kv));
-    if (c->force_twopass || (getenv("FZ_HIST") && atoi(getenv("FZ_HIST")) == 0)) return 1;
+    if (c->force_twopass || (fz_dbg("FZ_HIST") && atoi(fz_dbg("FZ_HIST")) == 0)) return 1;
     // FZ_EXACT_EVIDENCE=1 (tests): the form that weighs every pair without classifying it first
-    const bool exact = getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0;
+    const bool exact = fz_dbg("FZ_EXACT_EVIDENCE") && atoi(fz_dbg("FZ_EXACT_EVIDENCE")) != 0;
     fz_exact_now() = exact || c->exact_evidence;
     const int r = fz_launch_hist<SRC>(c, src, kv, n, M, ko, lmap, levid, pdfs, exact);
     if (r <= 0) c->last_form = (exact || SRC::LMODE == 2) ? "k_hist<exact>" : "k_hist<screen>";
@@ -563,17 +563,17 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
         // the default where it applies: one pass, LDS histograms, no candidate lists, every weight and sum in fp64 (fz_hist.h); FZ_HIST=0
         // keeps k_fused, FZ_EXACT_EVIDENCE=1 (tests) the form that weighs every pair without classifying it first.  like_opts.exact_evidence
         // matters to k_fused's weight-space body only (fp32 remainder of the evidence there)
-        const bool exact = getenv("FZ_EXACT_EVIDENCE") && atoi(getenv("FZ_EXACT_EVIDENCE")) != 0;
+        const bool exact = fz_dbg("FZ_EXACT_EVIDENCE") && atoi(fz_dbg("FZ_EXACT_EVIDENCE")) != 0;
         fz_exact_now() = exact || c->exact_evidence;
         double share = -2.0;                                     // not sampled yet
-        if (!getenv("FZ_HIST") || atoi(getenv("FZ_HIST")) != 0) {
+        if (!fz_dbg("FZ_HIST") || atoi(fz_dbg("FZ_HIST")) != 0) {
             // The classifier pays when it drops most pairs: with 7 % of the pairs within wt_thresh of the best (41 % above the drop
             // bar) it runs level with the form that weighs every pair directly (53.4 vs 54.9 ms per 2.6e10 pairs), with 3 % ahead of
             // it (46.0 vs 55.2); for broader likelihoods (faint data: the reference's own mock sits at 41 %; bench.py --noise-scale
             // 3 / 10: 53 % / 95 %) the direct form is the faster one.  FZ_NOLIST=1 / 0 forces / forbids the switch.
             bool broad = false;
             if (!exact) {
-                const char* e = getenv("FZ_NOLIST");
+                const char* e = fz_dbg("FZ_NOLIST");
                 const int want = e ? atoi(e) : -1;
                 if (want < 0 && n >= 16384) { share = fz_nolist_probe<SRC>(c, src, kv, n, M, ko); broad = share > 0.12; }
                 else broad = want == 1;
@@ -600,9 +600,9 @@ int fz_launch_fitpredict(fz_ctx* c, const SRC& src, int64_t n, int64_t M, const 
             // 128 VGPRs, and the body then spills inside the model loop (3-4x slower); 12 waves (168 VGPRs) do not
             if (tw == 2 && nw == 16 && fz_use_wspace(src) && (SRC::LMODE == 0 || SRC::NB >= 7)) nw = 12;
             // ... and so does the class-sorted stack of many dictionary widths (its PDF stage keeps a 12-register result row)
-            if (tw == 2 && nw == 16 && fz_use_wspace(src) && kv.kmode == fz::KDE_DICT && c->mc_ok && !getenv("FZ_NO_MC")) nw = 12;
+            if (tw == 2 && nw == 16 && fz_use_wspace(src) && kv.kmode == fz::KDE_DICT && c->mc_ok && !fz_dbg("FZ_NO_MC")) nw = 12;
             else if (tw == 4 && SRC::PREF_2x8) { tw = 2; nw = 8; }
-            if (const char* e = getenv("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
+            if (const char* e = fz_dbg("FZ_FUSED_CFG")) sscanf(e, "%d,%d", &tw, &nw);
             if (tw == 4 && nw == 8) r = fz_launch_fused_tw<SRC, 4, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 8) r = fz_launch_fused_tw<SRC, 2, 8>(c, src, kv, n, M, ko, lmap, levid, pdfs);
             else if (tw == 2 && nw == 16) r = fz_launch_fused_tw<SRC, 2, 16>(c, src, kv, n, M, ko, lmap, levid, pdfs);

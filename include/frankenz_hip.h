@@ -86,6 +86,13 @@ typedef struct fz_timing {
 } fz_timing;
 
 const char* fz_last_error(void);
+
+/* Test / tuning switches.  The library does not read the environment: every switch that selects an alternative kernel form, a
+ * launch geometry or a diagnostic (the "FZ_..." names listed in INTEGRATION.md section 5; none of them changes a result beyond
+ * rounding) is set through this ONE call.  spec = "NAME=value;NAME=value;..." REPLACES the whole set (NULL or "": none set).
+ * Process-wide; not to be called while another entry point runs.  The Python layer forwards the process's FZ_* environment
+ * variables through it before each call (frankenz_amd/_lib.py), which is how the tests and tools/ set them. */
+int  fz_debug_opts(const char* spec);
 int  fz_device_count(void);
 
 int  fz_ctx_create(int device, fz_ctx** out);

@@ -197,3 +197,18 @@ def test_the_listing_check_catches_a_touched_row_register(tmp_path, monkeypatch)
     f.write_text(bad)
     monkeypatch.setattr(ge, "PLANE_ISA", str(f))
     assert any('touches' in p for p in ge.check_hand_scheduled())
+
+
+def test_switches_reach_the_library_through_one_call(monkeypatch):
+    """the C library reads no environment variable: the loader hands the process's FZ_* variables over through fz_debug_opts
+    before a call whenever they have changed (include/frankenz_hip.h)"""
+    from frankenz_amd import _lib
+    lib = _lib.load()
+    src = open(os.path.join(ROOT, 'frankenz_amd', 'csrc', 'frankenz_hip.hip')).read() + open(os.path.join(ROOT, 'frankenz_amd', 'csrc', 'fz_launch.h')).read()
+    assert 'getenv(' not in src
+    monkeypatch.setenv('FZ_ABI_TEST_SWITCH', '7')
+    lib.fz_device_count()                           # any entry point: the set is synchronised first
+    assert 'FZ_ABI_TEST_SWITCH=7' in lib._sent
+    monkeypatch.delenv('FZ_ABI_TEST_SWITCH')
+    lib.fz_device_count()
+    assert 'FZ_ABI_TEST_SWITCH' not in lib._sent

@@ -12,4 +12,6 @@ TAG=${TAG}_headline tools/pmc.sh > /dev/null 2>&1; echo "pmc headline done"
 TAG=${TAG}_general BENCH_ARGS="--model-err varying" tools/pmc.sh > /dev/null 2>&1; echo "pmc general done"
 TAG=${TAG}_modeB BENCH_ARGS="--mode B" tools/pmc.sh > /dev/null 2>&1; echo "pmc modeB done"
 TAG=${TAG}_catalogue BENCH_ARGS="--model-err varying --mask-frac 0.02 --model-mask-frac 0.02" tools/pmc.sh > /dev/null 2>&1; echo "pmc catalogue done"
+TAG=${TAG}_catalogue_widths BENCH_ARGS="--model-err varying --mask-frac 0.02 --model-mask-frac 0.02 --label-err varying" tools/pmc.sh > /dev/null 2>&1; echo "pmc catalogue widths done"
+TAG=${TAG}_modeC NOBJ=20000 NMODEL=10000 BENCH_ARGS="--mode C --model-err varying" tools/pmc.sh > /dev/null 2>&1; echo "pmc mode C done"
 ls gpurun_out/pmc_${TAG}_*.txt
