@@ -1063,13 +1063,14 @@ static int fit_predict_impl(fz_ctx* c, double* x, double* xe, double* xm, int64_
             // ... with one dictionary kernel or many (per-model label errors: the layout is ordered by width class first).  Mask-free data
             // with many widths keep k_fused's class-sorted stack (80 against 112 ms per 2.6e10 pairs: the per-class convolutions cost both
             // kernels the same, and k_fused's weight-space loop has no group-by-group tiles at the class boundaries); FZ_HIST_SEG_MC=1
-            // sends them here too (tests).
+            // sends them here too (tests); FZ_HIST_SEG_FORCE=1 sends mask-free single-width data through the segmented form (tests; the
+            // measure of what the form itself costs: +16 % / +25 % / +11 % on the same data in modes Ai / A / B).
             const char* smc = fz_dbg("FZ_HIST_SEG_MC");
             const bool many_widths = c->label_mode == 1 && !c->single_cls;
             const bool masks = c->models_real_masked || var == VAR_MASKED;
             const bool seg_mc = many_widths && c->mc_ok && !(smc && atoi(smc) == 0) && (masks || (smc && atoi(smc) == 1));
             if ((var == VAR_MASKED || var == VAR_FAST) && c->BT == c->B && !c->prior.tab &&
-                (many_widths ? seg_mc : (c->models_real_masked || (var == VAR_MASKED && mode == 0)))) {
+                (many_widths ? seg_mc : (c->models_real_masked || (var == VAR_MASKED && mode == 0) || fz_dbg("FZ_HIST_SEG_FORCE")))) {
                 const int r0 = run_fitpredict(c, mode, VAR_SEG, o->dim_prior, n, ko, d_lm, d_le, d_pdf);
                 if (r0 < 0) return r0;
                 done = (r0 == 0);

@@ -354,7 +354,12 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
     };
     double rK = 1.0;                                                    // SEG: 1 / K of the pattern in force
     auto exactw_tab = [&](double c2, const FastTabs& t, auto small) {
-        if constexpr (SEG) return hist_exactw_rt8<decltype(small)::value>(c2, wpr, K, rK, t);
+        if constexpr (SEG) {
+            // (the common pattern -- every band observed on both sides -- has the compile-time power: the cheaper form, behind a wave-uniform
+            //  branch.  The free scale only, where EVERY pair is weighed: 72 -> 67 ms per 2.6e10 pairs; the screen forms lose 0-3 ms to it.)
+            if constexpr (SRC::LMODE == 2) { if (wpr == WP) return hist_exactw<WP, decltype(small)::value>(c2, t); }
+            return hist_exactw_rt8<decltype(small)::value>(c2, wpr, K, rK, t);
+        }
         else if constexpr (KRT) return hist_exactw_rt<decltype(small)::value>(c2, wpr, t);
         else return hist_exactw<WP, decltype(small)::value>(c2, t);
     };
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
                     if (am) { Cand e; e.lnl = c2; e.j = tag; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                     hs.namb[o] += np;
+                    if constexpr (SEG) hs.namb[o] = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                 } else hs.namb[o] = -1;                           // overflowed: nothing more is stored, the object goes to the sweep
             }
         };
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
             int tag = (int)rtag[o * CAP + rest + lane];
             const bool act = lane < n;
             settle(o, act, c2, tag, badc);
-            hs.pend[o] = rest;
+            hs.pend[o] = SEG ? __builtin_amdgcn_readfirstlane(rest) : rest;
         };
         // SEG with many dictionary widths (kv.seg_nrank > 1; the segments are ordered by width class first): the histogram holds the
         // weights of ONE class.  When the class of the model stream changes -- and at the finish -- the row is divided by the class's
@@ -605,10 +611,15 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
         // are the old pattern's; `flush` in step_body: the loop's own drain site, so that this rare code holds no second copy of the
         // settle and leaves the registers of the model loop alone).
         auto seg_switch = [&](int sw) {
-            const uint32_t jb = obits & kv.seg_mask[sw & 0x3fff];     // bands both sides observe (wave-uniform)
+            // bands both sides observe (wave-uniform; said to be so where that helps the register allocation: with per-model errors the
+            // hint costs 3 ms per 2.6e10 pairs, in the other modes it saves up to 4)
+            constexpr bool UH = SRC::LMODE != 0;
+            uint32_t jb = obits & kv.seg_mask[sw & 0x3fff];
+            if constexpr (UH) jb = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb);
             const int nd = __popc(jb);
             const bool dp = src.lp.dim_prior != 0;
             wpr = dp ? nd - KOFF : 0;
+            if constexpr (UH) wpr = __builtin_amdgcn_readfirstlane(wpr);
             segbad = wpr == -1;
             if (wpr < 0) wpr = 1;                                      // (below -1 kok is false: the object goes to the sweep; the arithmetic stays finite)
             ndcur = nd;
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                 else ob[0].v[b] = on ? ob[0].v[b] : 0.0;
                 ob[0].x[b] = on ? ob[0].x[b] : 0.0;
             }
-            segcur = sw & 0x3fff;                                      // (without the pad-slots flag: a flagged group never passes for "the pattern in force")
+            segcur = UH ? __builtin_amdgcn_readfirstlane(sw & 0x3fff) : (sw & 0x3fff);      // (without the pad-slots flag: a flagged group never passes for "the pattern in force")
         };
 
         // chi2 of one pair from the wave's (effective) object row: the forms of the model loop, also used by the segmented form's
@@ -766,6 +777,7 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             if (hs.namb[o] >= 0 && hs.namb[o] + np <= cap) {
                                 if (am) { Cand e; e.lnl = c2[0][o]; e.j = ptag[0]; e.pad = SEG ? (ndcur | (mcw ? kv.seg_rank[segcur] << 8 : 0)) : 0; ambw[(size_t)o * cap + hs.namb[o] + pre] = e; }
                                 hs.namb[o] += np;
+                    if constexpr (SEG) hs.namb[o] = __builtin_amdgcn_readfirstlane(hs.namb[o]);
                             } else hs.namb[o] = -1;
                         }
                     }
@@ -805,6 +817,9 @@ __global__ __launch_bounds__(NW * 64) void k_hist(SRC src_, const KdeView* __res
                             if (c) { rc2[o * CAP + slot] = c2[q][o]; rtag[o * CAP + slot] = (tag_t)ptag[q]; }
 #endif
                             hs.pend[o] += __builtin_popcountll(mask);
+                            // (the segmented kernels run out of scalar registers: without this the fill level lives in a vector register and
+                            //  every `while (pend >= DTHR)` below becomes a divergent loop)
+                            if constexpr (SEG) hs.pend[o] = __builtin_amdgcn_readfirstlane(hs.pend[o]);
                         }
                         if constexpr (!FZ_HIST_REFRESH_TILE) {
                             if (++hs.tick == hs.next) {                           // steps 1, 2, 4, 8, 16, then every FZ_HIST_REFRESH-th

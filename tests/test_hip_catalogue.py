@@ -220,3 +220,23 @@ def test_many_dictionary_widths_on_the_one_pass_kernel(mode, masks, monkeypatch)
         np.testing.assert_allclose(p[ok].sum(axis=1), 1.0, rtol=1e-12)
     fin = np.isfinite(p1).all(axis=1) & ok
     close(p0[fin], p1[fin], rtol=1e-7, atol=1e-13); close(le0[fin], le1[fin], **EVID)
+
+
+@pytest.mark.parametrize('mode', ['A', 'Ai', 'B'])
+def test_segmented_form_on_mask_free_data(mode, monkeypatch):
+    """FZ_HIST_SEG_FORCE=1: the segmented kernel on data that does not need it (one segment, one pattern) -- the same PDFs, ln-max
+    and ln-evidence as the plain one-pass kernel, to rounding"""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    d, od = dicts()
+    rs = np.random.RandomState(77 + len(mode))
+    Y, Ye, Ym, X, Xe, Xm, z, ze = catalogue(rs, 4000, 700, 5, 'varying', 0.0, 0.0)
+    bf = BruteForce(Y, Ye, Ym)
+    run = lambda: bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, lprob_kwargs=MODES[mode], return_gof=True, save_fits=False,
+                                 verbose=False)
+    p0, (lm0, le0) = run()
+    assert 'segmented' not in get_engine().last_form()
+    monkeypatch.setenv('FZ_HIST_SEG_FORCE', '1')
+    p1, (lm1, le1) = run()
+    assert 'segmented' in get_engine().last_form()
+    close(p1, p0, rtol=1e-9, atol=1e-15); close(lm1, lm0, rtol=1e-13); close(le1, le0, **EVID64)
