@@ -291,3 +291,45 @@ def test_config5_substitute_stack_and_population_likelihood_at_catalogue_scale()
     np.testing.assert_allclose(lm[pick], rlm, rtol=1e-9)
     np.testing.assert_allclose(le[pick], rle, **EVID64)
     np.testing.assert_allclose(p[pick], rp, rtol=1e-7, atol=1e-14)
+
+
+@pytest.mark.parametrize('widths', [False, True])
+def test_catalogue_shape_at_full_size(widths):
+    """the bench's ``roofline_catalogue`` / ``roofline_catalogue_widths`` configurations at 1e5 x 1e5: per-model errors, 2 % of the object
+    bands and 2 % of the model bands missing, and (widths) per-model label errors -- the segmented form of k_hist, with the class
+    flushes in the second case.  Normalisation, max <= logsumexp <= max + ln M, shard invariance, and the oracle on a sample of
+    objects against the full model set; rows the reference leaves undefined (a pair without a common band) must be nan here too."""
+    from frankenz_amd import BruteForce
+    from frankenz_amd.engine import get_engine
+    n, m = 100000, 100000
+    Y, Ye, Ym, X, Xe, Xm, z, ze = problem(n, m, varying_errors=True, mask_frac=0.02)
+    Ym[np.random.RandomState(6).rand(m, 5) < 0.02] = 0.0
+    if widths:
+        ze = np.random.RandomState(78).uniform(0.01, 0.1, size=m)
+    d, od = dicts()
+    bf = BruteForce(Y, Ye, Ym)
+    with np.errstate(all='ignore'):
+        p, (lm, le) = bf.fit_predict(X.copy(), Xe.copy(), Xm.copy(), z, ze, label_dict=d, return_gof=True, save_fits=False, verbose=False)
+        assert get_engine().last_form() == 'k_hist<screen> (segmented models' + (', many widths)' if widths else ')')
+        fin = np.isfinite(p).all(axis=1)
+        assert fin.mean() > 0.99 and np.isnan(p[~fin]).all()
+        assert (p[fin] >= 0).all()
+        np.testing.assert_allclose(p[fin].sum(axis=1), 1.0, rtol=0, atol=1e-12)
+        assert np.all(le[fin] >= lm[fin] - 1e-12) and np.all(le[fin] <= lm[fin] + np.log(m) + 1e-9)
+        sl = slice(4242, 4242 + 5000)
+        p2, (lm2, le2) = bf.fit_predict(X[sl].copy(), Xe[sl].copy(), Xm[sl].copy(), z, ze, label_dict=d, return_gof=True, save_fits=False,
+                                        verbose=False)
+        f2 = fin[sl]
+        np.testing.assert_array_equal(np.isfinite(p2).all(axis=1), f2)
+        np.testing.assert_allclose(lm2[f2], lm[sl][f2], rtol=1e-13); np.testing.assert_allclose(le2[f2], le[sl][f2], **EVID64)
+        np.testing.assert_allclose(p2[f2], p[sl][f2], rtol=1e-11, atol=1e-15)
+        # the oracle on a sample: objects with and without missing bands, and up to five of the undefined ones
+        rs = np.random.RandomState(2)
+        masked = np.flatnonzero((Xm == 0).any(axis=1) & fin)
+        pick = np.concatenate([rs.choice(n, 30, replace=False), rs.choice(masked, 25, replace=False), np.flatnonzero(~fin)[:5]])
+        rp, rlm, rle = fo.bruteforce_fit_predict(X[pick].copy(), Xe[pick].copy(), Xm[pick].copy(), Y, Ye, Ym, z, ze, label_dict=od)
+    ok = np.isfinite(rp).all(axis=1)
+    np.testing.assert_array_equal(ok, fin[pick])
+    np.testing.assert_allclose(lm[pick][ok], rlm[ok], rtol=1e-9)
+    np.testing.assert_allclose(le[pick][ok], rle[ok], **EVID64)
+    np.testing.assert_allclose(p[pick][ok], rp[ok], rtol=1e-7, atol=1e-14)
