@@ -213,6 +213,30 @@ def sub_modec(eng, dev, torch, pd, steps=2):
             "note": "evals/s counts each (object, model) pair once, whatever its iteration count"}
 
 
+def sub_nz_stack(eng, dev, torch, d_pdf, N, G, steps=3):
+    """BASELINE configs[4], second half: one sweep of the hierarchical n(z) sampler over the PDFs of the step -- the per-object
+    categorical draw from pdf_i * nz (samplers.py:498-499, 519-520) and the ln-likelihood of the stack (samplers.py:60-80).  Both read
+    the (N, G) PDF stack once: HBM-bound, 8 B per PDF entry each."""
+    nz = torch.full((G,), 1.0 / G, dtype=torch.float64, device=dev)
+    u = torch.rand(N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    bins = torch.empty(N, dtype=torch.int64, device=dev); counts = torch.zeros(G, dtype=torch.int64, device=dev)
+    overlap = torch.empty(N, dtype=torch.float64, device=dev)
+    eng.nz_assign(d_pdf, nz, u, bins, counts, n=N); ll = eng.overlap_nz(d_pdf, nz, None, 0.0, overlap, n=N); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        counts.zero_()
+        eng.nz_assign(d_pdf, nz, u, bins, counts, n=N)
+        ll = eng.overlap_nz(d_pdf, nz, None, 0.0, overlap, n=N)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    gbs = 2 * N * G * 8 / dt / 1e9
+    return {"workload": "BASELINE configs[4], the n(z) half: one Gibbs sweep (categorical draw per object + ln-likelihood of the stack) over "
+                        "%d PDFs x %d grid points" % (N, G), "value": N / dt, "unit": "objects/s per sweep", "ms_per_step": dt * 1e3,
+            "counts_sum_to_N": bool(int(counts.sum().item()) == N), "loglike_finite": bool(np.isfinite(ll)),
+            "roofline": {"bound": "hbm", "kernel": "k_nz_assign + k_overlap", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pdf_entry": 16, "note": "algorithmic: the PDF stack read once by each kernel"}}
+
+
 def sub_knn(dev, torch, pd, local, steps=2):
     """BASELINE configs[3] slice: NearestNeighbors.fit_predict(save_fits=False), K = 25 Monte-Carlo feature sets, k = 20, 1e5 objects x
     1e5 models, device resident.  The roofline figure is the matrix pipe's: the exact search multiplies 64-model tiles of fp32
@@ -676,6 +700,7 @@ def main():
                 a2 = N * M / (max(tm2["n_fused"], 1) / 2) * fl / (ms2 * 1e-3) / 1e12
                 return {"value": N * M / dt2, "unit": "evals/s", "ms_per_step": dt2 * 1e3, "achieved": a2, "peak": FP64_VALU_PEAK_TFLOPS,
                         "frac": a2 / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": fl, "avg_launch_ms": ms2, "kernel": eng.last_form()}
+            out["nz_stack"] = _sub(lambda: sub_nz_stack(eng, dev, torch, d_pdf, N, pd.Ngrid))      # (on the PDFs of the timed steps)
             out["roofline_fp64"] = dict(out["roofline"], value=value, ms_per_step=dt / args.steps * 1e3,
                                         note="the headline line IS the all-fp64 form since round 4 (same numbers, kept under the old key)")
             out["roofline_general"] = dict(extra(Ye * np.random.RandomState(77).uniform(0.5, 1.5, size=Ye.shape), {}, "A"),

@@ -319,16 +319,23 @@ static __global__ __launch_bounds__(256) void k_overlap(const double* __restrict
 // with integer atomics (order-free).  A row without mass (total <= 0 or not finite) gets bin -1.
 static __global__ __launch_bounds__(256) void k_nz_assign(const double* __restrict__ pdfs, int64_t N, int G,
                                                           const double* __restrict__ nz, const double* __restrict__ u,
-                                                          int64_t* __restrict__ bins, unsigned long long* __restrict__ counts) {
+                                                          int64_t* __restrict__ bins, unsigned long long* __restrict__ counts, int staged) {
+    extern __shared__ double s_w[];                               // [4][G]: the wave's row of p[g] * nz[g]
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
-    const double* p = pdfs + i * G;
+    // the row comes in with lanes ALONG the grid (512 contiguous bytes per load; a lane reading its own run straight from memory
+    // strides the wave's 64 addresses by `per` doubles: 2 TB/s) and waits in LDS, weighted, for the lanes' runs
+    // (staged == 0: a grid too long for four rows of LDS -- the lanes read their runs from memory)
+    double* pl = s_w + (size_t)(threadIdx.x >> 6) * G;
+    const double* pg = pdfs + i * G;
+    if (staged) for (int g = lane; g < G; g += 64) pl[g] = pg[g] * nz[g];
+    auto W = [&](int g) { return staged ? pl[g] : pg[g] * nz[g]; };
     // every lane owns a CONTIGUOUS run of grid points, so that the running sum is monotone across lanes
     const int per = (G + 63) / 64;
     const int g0 = lane * per, g1 = min(G, g0 + per);
     double s = 0.0;
-    for (int g = g0; g < g1; ++g) s += p[g] * nz[g];
+    for (int g = g0; g < g1; ++g) s += W(g);
     // exclusive prefix over the lanes (Hillis-Steele on the lane sums)
     double incl = s;
 #pragma unroll
@@ -345,7 +352,7 @@ static __global__ __launch_bounds__(256) void k_nz_assign(const double* __restri
         const int owner = at ? __builtin_ctzll(at) : 63 - __builtin_clzll(mass);
         if (lane == owner) {
             double c = excl; int g = g0, last = g0;
-            for (; g < g1; ++g) { const double w = p[g] * nz[g]; if (w > 0.0) last = g; c += w; if (at && c > target) break; }
+            for (; g < g1; ++g) { const double w = W(g); if (w > 0.0) last = g; c += w; if (at && c > target) break; }
             bin = (g < g1) ? g : last;                           // (run exhausted: by rounding, or at the top: its last point with mass)
             bins[i] = bin;
             atomicAdd(&counts[bin], 1ull);
