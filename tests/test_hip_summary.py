@@ -217,3 +217,28 @@ def test_nz_assign_law_against_the_reference_draws():
         stat, dof, rare = _two_sample_chi2(dc, rc[k])
         assert stat < dof + 5 * np.sqrt(2 * dof) + 10, (k, stat, dof)
         assert abs(int(rare[0]) - int(rare[1])) < 10 + 5 * np.sqrt(rare[0] + rare[1] + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('G', [701, 1536, 1537, 2500])
+def test_nz_assign_row_staging_and_long_grids(G):
+    """k_nz_assign keeps the weighted row in LDS for grids up to 1 536 points and reads the lanes' runs from memory beyond: the same
+    bins as the oracle's inverse CDF on the same uniforms either way (a bin may differ only at a CDF edge within rounding)"""
+    from frankenz_amd import samplers
+    rs = np.random.RandomState(G)
+    N = 3000
+    cen = rs.uniform(0.05, 0.95, N)[:, None] * G
+    pdfs = np.exp(-0.5 * ((np.arange(G)[None, :] - cen) / rs.uniform(3, 40, N)[:, None]) ** 2)
+    pdfs[pdfs < 1e-12] = 0.0
+    pdfs /= pdfs.sum(axis=1)[:, None]
+    nz = rs.dirichlet(np.full(G, 0.9))
+    u = rs.rand(N)
+    counts, bins = samplers.nz_assign(nz, pdfs, u=u, return_bins=True)
+    rc, rb, cdf = fo.nz_assign(nz, pdfs, u)
+    diff = np.flatnonzero(bins != rb)
+    for i in diff:
+        t = u[i] * cdf[i, -1]
+        lo_, hi_ = min(bins[i], rb[i]), max(bins[i], rb[i])
+        assert abs(cdf[i, lo_] - t) <= 1e-12 * cdf[i, -1] and cdf[i, hi_ - 1] - cdf[i, lo_] <= 1e-12 * cdf[i, -1]
+    assert len(diff) <= 3 and counts.sum() == N
+    np.testing.assert_array_equal(counts, np.bincount(bins, minlength=G))
