@@ -167,3 +167,22 @@ def test_mode_c_fused_pdfs_with_and_without_the_in_kernel_final_pass(M, monkeypa
         outs.append((p, lm, le))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-12, atol=1e-15)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('zero_model', [0, 7])
+def test_mode_c_with_a_model_whose_ln_like_is_not_a_number(zero_model, monkeypatch):
+    """a model of all-zero fluxes has shape 0 and scale 0 / 0: its ln-like is nan in every pass.  pdf.py:199 takes the builtin ``max``
+    over the errors, which skips a nan unless it is element 0 -- then the loop ends at once.  Such a model set is not "tame": the
+    library keeps it off the reciprocal-based solve (and with it off k_modec_rounds, whose stop rule assumes finite errors) and runs
+    the IEEE kernel -- asserted here -- which must give the oracle's pass counts and rows for both placements."""
+    Y, Ye, Ym, X, Xe, Xm = problem(3000, 8, 31 + zero_model)
+    Y[zero_model] = 0.0
+    with np.errstate(all='ignore'):
+        want = oracle_rows(Y, Ye, Ym, X, Xe, Xm, 1e-4, range(8))
+        bf, niter, info = hip_fit(Y, Ye, Ym, X, Xe, Xm, 1e-4)
+    assert info[2] == 1 and info[0] == 0                       # one block per object, one iteration per record read, IEEE: no re-run
+    for i, w in enumerate(want):
+        assert niter[i] == w[5], (zero_model, i, niter[i], w[5])
+        fin = np.isfinite(w[0])
+        np.testing.assert_array_equal(np.isfinite(bf.fit_lnlike[i]), fin)
+        np.testing.assert_allclose(bf.fit_lnlike[i][fin], w[0][fin], rtol=1e-9, atol=1e-9)
