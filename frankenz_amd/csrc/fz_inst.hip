@@ -165,6 +165,7 @@ static int run_modec(fz_ctx* c, int64_t n, const fz_like_opts* o, const SubsetVi
     ModeCState st; st.s = c->d_mc[0].as<double>(); st.l = c->d_mc[1].as<double>(); st.c = c->d_mc[2].as<double>();
     st.sh = c->d_mc[3].as<double>(); st.err = c->d_mcerr.as<unsigned long long>(); st.errhi = st.err + n; st.firstnan = c->d_mcfn.as<int>();
     st.lnl_only = 0; st.lgtab = c->d_lgB.as<double>();
+    st.qhead = nullptr; st.rfixed = fz_dbg("FZ_MODEC_RFIXED") ? atoi(fz_dbg("FZ_MODEC_RFIXED")) : 0;
     FZCHK(c->d_mcniter.ensure(n * 4)); st.niter = c->d_mcniter.as<int>(); c->mc_niter_n = n;
     HIPCHK(hipMemsetAsync(st.niter, 0, n * 4, c->stream));
     // Active-object lists and their lengths live on the device and alternate between two slots; the host

@@ -47,6 +47,7 @@ struct ModeCState {
     int lnl_only;
     const double* lgtab;
     int* qhead;                // (1) k_modec_rounds: the next object of the launch (zeroed by the host)
+    int rfixed;                // k_modec_rounds, tests (FZ_MODEC_RFIXED): every round this long instead of predicted -- rounds that run past the stop
     int* niter;                // (Nc) iterations each object took (the count of pdf.py:199's loop passes); may be nullptr
 };
 
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(TPB) void k_modec_rounds(MC mc, ModeCState st, int6
                         if (iters < 6) n *= 0.8;
                     }
                     Rn = (n >= (double)FZ_MCR_RMAX) ? FZ_MCR_RMAX : ((n >= 1.0) ? (int)n : 1);      // (NaN: 1)
+                    if (st.rfixed > 0) Rn = st.rfixed < FZ_MCR_RMAX ? st.rfixed : FZ_MCR_RMAX;
                     if (Rn > max_iter - iters) Rn = max_iter - iters;
                 }
 #ifdef FZ_MCR_DEBUG

@@ -186,3 +186,24 @@ def test_mode_c_with_a_model_whose_ln_like_is_not_a_number(zero_model, monkeypat
         fin = np.isfinite(w[0])
         np.testing.assert_array_equal(np.isfinite(bf.fit_lnlike[i]), fin)
         np.testing.assert_allclose(bf.fit_lnlike[i][fin], w[0][fin], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('M', [3000, 10000, 20000])
+def test_mode_c_rounds_that_run_past_the_stop_are_redone(M, monkeypatch):
+    """FZ_MODEC_RFIXED=7: every round of k_modec_rounds is seven iterations long instead of sized from the error's decay, so most
+    objects reach the reference's stop in the MIDDLE of a round.  Their models have then moved past the state the reference returns:
+    the kernel must notice (the first iteration without a model above ltol is not the round's last) and hand the object to the IEEE
+    kernel -- same pass counts and rows as the oracle, and the hand-over count says it happened."""
+    Y, Ye, Ym, X, Xe, Xm = problem(M, 10, 77 + M // 1000)
+    want = oracle_rows(Y, Ye, Ym, X, Xe, Xm, 1e-4, range(10))
+    monkeypatch.setenv('FZ_MODEC_RFIXED', '7')
+    bf, niter, info = hip_fit(Y, Ye, Ym, X, Xe, Xm, 1e-4)
+    assert info[2] == 3 and info[0] >= 5, info                  # ((T - 2) mod 7 == 0 for about one object in seven only)
+    for i, w in enumerate(want):
+        assert niter[i] == w[5], (M, i, niter[i], w[5])
+        np.testing.assert_allclose(bf.fit_lnlike[i], w[0], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(bf.fit_scale[i], w[3], rtol=1e-9, atol=1e-11)
+    monkeypatch.delenv('FZ_MODEC_RFIXED')
+    _, niter2, info2 = hip_fit(Y, Ye, Ym, X, Xe, Xm, 1e-4)
+    np.testing.assert_array_equal(niter2, niter)
+    assert info2[0] == 0                                        # predicted rounds: nothing handed over
